@@ -50,10 +50,10 @@ def test_gkr_random_inputs():
     rng = random.Random(42)
     fid, name = O.FR381, "bls12_381_fr"
     p = M.P[name]
-    layers = [[(0, 1, 0, O.MUL), (0, 1, 1, O.ADD)],
-              [(0, 1, 0, O.ADD), (2, 3, 1, O.MUL), (1, 2, 2, O.MUL), (0, 3, 3, O.ADD)],
-              [(0, 1, 0, O.MUL), (2, 3, 1, O.ADD), (4, 5, 2, O.MUL), (6, 7, 3, O.ADD), (0, 7, 4, O.ADD),
-               (1, 6, 5, O.MUL), (2, 5, 6, O.ADD), (3, 4, 7, O.MUL)]]
+    # the reference ties width to depth: layer i reads a 2^(i+1)-entry layer (arithmetic_circuit.rs:166-178)
+    layers = [[(0, 1, 0, O.MUL), (1, 0, 1, O.ADD)],
+              [(0, 3, 0, O.ADD), (2, 1, 1, O.MUL)],
+              [(0, 1, 0, O.MUL), (2, 3, 1, O.ADD), (7, 5, 2, O.MUL), (6, 4, 3, O.ADD), (0, 7, 3, O.MUL)]]
     inputs = [rng.randrange(p) for _ in range(8)]
     proof = O.gkr_prove(fid, layers, O.from_ints(fid, inputs))
     mp = M.gkr_prove(layers, inputs, p)
@@ -61,6 +61,10 @@ def test_gkr_random_inputs():
     assert O.to_ints(fid, proof["circuit_output"]) == mp["circuit_output"]
     assert O.gkr_verify(fid, layers, proof, O.from_ints(fid, inputs))
     assert M.gkr_verify(layers, mp, inputs, p)
+    # a layer whose width does not match its depth panics in ProductPolynomial::new
+    bad = [[(0, 1, 0, O.MUL)], [(0, 1, 0, O.ADD), (2, 3, 1, O.MUL), (4, 5, 2, O.MUL), (6, 7, 3, O.ADD)]]
+    with pytest.raises(O.OraclePanic):
+        O.gkr_prove(fid, bad, O.from_ints(fid, inputs))
 
 
 def test_kzg_random():
