@@ -1,0 +1,128 @@
+"""bench.py -- field-mul/s of the 2^24 MLE fold (BASELINE.json metric) on N MI355X GPUs.
+
+A step = one `partial_evaluate(table, 0, r)` pass over one resident 2^24-entry BLS12-381 Fr
+table per GPU (2^23 field multiplications, 96 algorithmic bytes each).  Weak scaling: every
+rank folds its own low-bit shard; the data path has no collective.
+Prints ONE JSON line on rank 0.  See DESIGN.md section 5 for the roofline accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log-n", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as G
+    zk = G.import_package()
+    from zkmle_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: zkmle_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    _lib.check(zk.lib().zk_init(local_rank))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    field = zk.FR381
+    n = 1 << args.log_n
+    half = n // 2
+    MP = zk.MultilinearPolynomial
+    table = MP.random(field, n, 0x5EED0005 + rank)       # shard-wise on-device generation
+    out = MP.alloc(field, half)
+    r = np.zeros(4, np.uint64)
+    _lib.check(zk.lib().zk_host_fill_random(field, 0x5EED0005, n, 1, _lib.p64(r)))
+    L = zk.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        _lib.check(L.zk_mle_fold(table._h, 0, _lib.p64(r), out._h, stream))
+        out_len_fix()
+
+    def out_len_fix():
+        pass
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    muls = half * args.steps * world
+    value = muls / dt
+    algo_bytes = 96.0 * half                               # per launch: 2 x 32 B read + 32 B write per mul
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    result = {
+        "metric": "field-mul/s (2^24 MLE fold)", "value": value, "unit": "field-mul/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (BLS12-381 Fr, Montgomery)",
+        "data": "synthetic",
+        "config": {"workload": f"{args.log_n}-variable MLE fold (partial_evaluate var 0), BLS12-381 Fr, "
+                               f"2^{args.log_n}-entry table per GPU", "log_n": args.log_n, "field": "bls12_381_fr",
+                   "sharding": "low-bit shard per rank, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                     "traffic": None, "kernel": "fold_kernel<Fr381>", "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_launch": algo_bytes},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(zk, field)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(zk, field):
+    """the oracle's reference-faithful single-thread fold, timed on this host on a bounded sample"""
+    import numpy as np
+    from oracle import oracle as O
+    from zkmle_amd import _lib
+    log_n = 20
+    n = 1 << log_n
+    tab = np.zeros((n, 4), np.uint64)
+    _lib.check(zk.lib().zk_host_fill_random(field, 0x5EED0005, 0, n, _lib.p64(tab)))
+    r = tab[3].copy()
+    O.bench_fold(field, tab, r, 1)
+    reps = 20
+    secs = O.bench_fold(field, tab, r, reps)
+    return {"value": (n // 2) * reps / secs, "unit": "field-mul/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} folds of a 2^{log_n}-entry Fr table (same generator), reference allocation pattern, 1 thread"}
+
+
+if __name__ == "__main__":
+    main()

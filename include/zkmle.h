@@ -1,0 +1,116 @@
+/*
+ * zkmle.h -- C ABI of libzkmle_amd.so: the MI355X (gfx950) implementation of the multilinear
+ * hot path of casweeney/zk-cryptography-research-implementations.
+ *
+ * The reference has no FFI layer: its path is reached through generic Rust items.
+ * Each entry point below replaces the reference item cited next to it; the Rust shim that binds
+ * them is shown in INTEGRATION.md (rust_shim/ holds its source).
+ *
+ * Conventions
+ *   - field elements: `limbs` little-endian u64 limbs in Montgomery form, R = 2^(64*limbs) -- the
+ *     in-memory layout of an arkworks `Fp`, so `&[Fr]` / `Vec<F>` can be passed by pointer;
+ *   - tables: contiguous arrays of elements; index bit (n-1-v) <-> variable v (variable 0 = MSB),
+ *     evaluation_form.rs:76-80;
+ *   - every function returns a zk_status; precondition failures that PANIC in the reference
+ *     return the matching negative code and never abort (zk_status_message gives the
+ *     reference's panic text);
+ *   - `zk_table` handles own device (HBM) memory; host pointers stay owned by the caller;
+ *   - a handle is used by one thread at a time; the library is re-entrant after zk_init.
+ * The library NEVER falls back to a CPU path: without a usable HIP device every compute entry
+ * point returns ZK_E_NO_DEVICE.
+ */
+#ifndef ZKMLE_H
+#define ZKMLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { ZK_FR381 = 0, ZK_FQ381 = 1, ZK_BN254_FQ = 2, ZK_BN254_FR = 3 } zk_field;
+
+typedef enum {
+    ZK_OK = 0,
+    ZK_E_NOT_POW2 = -1,     /* "Evaluated values must be a power of 2"  evaluation_form.rs:13 */
+    ZK_E_LEN_MISMATCH = -2, /* evaluation_form.rs:112,129-132,149-153 */
+    ZK_E_NVARS = -3,        /* "different number of variables" product_polynomial.rs:16-21, sum_polynomial.rs:17-23 */
+    ZK_E_NEED_TWO = -4,     /* product_polynomial.rs:59-62, sum_polynomial.rs:58-61 */
+    ZK_E_KZG_LEN = -5,      /* multilinear_kzg.rs:29-33,55-64 */
+    ZK_E_RANGE = -6,        /* implicit index / underflow panics */
+    ZK_E_ARG = -7,          /* bad argument at the C boundary (no reference counterpart) */
+    ZK_E_NOMEM = -8,
+    ZK_E_NO_DEVICE = -9,    /* no usable HIP device: the product path has no CPU fallback */
+    ZK_E_HIP = -10,         /* a HIP runtime call failed; see zk_last_error */
+    ZK_E_NOT_INIT = -11     /* "Can't prove without init" prover.rs:36 */
+} zk_status;
+
+const char *zk_status_message(int status);
+const char *zk_last_error(void);      /* thread-local detail for ZK_E_HIP */
+const char *zk_version(void);
+
+/* ---- device ------------------------------------------------------------------------------- */
+int zk_device_count(int *count);
+int zk_init(int device);              /* select the device for the calling thread's later calls */
+int zk_field_limbs(int field);        /* u64 limbs per element (4 or 6), negative on bad field */
+int zk_device_synchronize(void);
+
+/* ---- device-resident tables ----------------------------------------------------------------
+ * MultilinearPolynomial<F>{evaluated_values: Vec<F>}  evaluation_form.rs:7-18 */
+typedef struct zk_table zk_table;
+int zk_table_alloc(int field, size_t len, zk_table **out);                 /* uninitialised */
+int zk_table_upload(int field, const uint64_t *host, size_t len, zk_table **out);  /* MultilinearPolynomial::new :12 (asserts pow2) */
+int zk_table_download(const zk_table *t, uint64_t *host);
+int zk_table_free(zk_table *t);
+size_t zk_table_len(const zk_table *t);
+int zk_table_field(const zk_table *t);
+void *zk_table_device_ptr(zk_table *t);                                    /* raw HBM pointer */
+int zk_table_wrap(int field, void *device_ptr, size_t len, zk_table **out); /* non-owning view of caller's HBM */
+int zk_table_clone(const zk_table *t, zk_table **out);
+/* synthetic benchmark data: element i = SplitMix64-derived 4 (6) words reduced mod p */
+int zk_table_fill_random(zk_table *t, uint64_t seed);
+/* host mirror of the generator (same bytes), for parity tests */
+int zk_host_fill_random(int field, uint64_t seed, size_t first, size_t count, uint64_t *out);
+
+/* ---- MLE operations on device tables --------------------------------------------------------
+ * every `stream` argument is a hipStream_t (NULL = the null stream) */
+/* partial_evaluate  evaluation_form.rs:61-106.  out: len/2 elements (out != in) */
+int zk_mle_fold(const zk_table *in, size_t var, const uint64_t *value, zk_table *out, void *stream);
+/* the same on raw device pointers (HBM-resident slices of a caller-managed buffer) */
+int zk_mle_fold_ptr(int field, const void *d_in, size_t len, size_t var, const uint64_t *value,
+                    void *d_out, void *stream);
+/* evaluate  evaluation_form.rs:21-33 : nvalues successive var-0 folds, element 0 */
+int zk_mle_evaluate(const zk_table *t, const uint64_t *values, size_t nvalues, uint64_t *out);
+/* convert_to_bytes  :35-43 : canonical big-endian bytes, len*8*limbs */
+int zk_mle_to_bytes(const zk_table *t, uint8_t *host_out);
+/* scalar_mul :49, add_polynomials :145, polynomial_tensor_add :108, polynomial_tensor_mul :125 */
+int zk_mle_scalar_mul(const zk_table *a, const uint64_t *scalar, zk_table *out, void *stream);
+int zk_mle_add(const zk_table *a, const zk_table *b, zk_table *out, void *stream);
+int zk_mle_sub_scalar(const zk_table *a, const uint64_t *scalar, zk_table *out, void *stream); /* multilinear_kzg.rs:74-78 */
+int zk_mle_tensor_add(const zk_table *wb, const zk_table *wc, zk_table *out, void *stream);
+int zk_mle_tensor_mul(const zk_table *wb, const zk_table *wc, zk_table *out, void *stream);
+/* iter().sum()  prover.rs:28 ; and split_polynomial_and_sum_each prover.rs:74-89 (out2: 2 elements) */
+int zk_mle_sum(const zk_table *t, uint64_t *out);
+int zk_mle_half_sums(const zk_table *t, uint64_t *out2);
+/* fused sumcheck round: fold by `value` AND return the folded table's two half sums (the next
+ * round's univariate) in one pass over HBM */
+int zk_mle_fold_half_sums(const zk_table *in, const uint64_t *value, zk_table *out, uint64_t *out2,
+                          void *stream);
+
+/* ---- stateless host-buffer conveniences (upload, compute on the GPU, download) --------------- */
+int zk_host_partial_evaluate(int field, const uint64_t *poly, size_t len, size_t var,
+                             const uint64_t *value, uint64_t *out);
+int zk_host_evaluate(int field, const uint64_t *poly, size_t len, const uint64_t *values,
+                     size_t nvalues, uint64_t *out);
+
+/* ---- host-side helpers (CPU, tiny: control path) -------------------------------------------- */
+int zk_fe_from_u64(int field, uint64_t v, uint64_t *out);
+int zk_fe_to_bytes_be(int field, const uint64_t *a, uint8_t *out);
+int zk_fe_from_le_bytes_mod_order(int field, const uint8_t *bytes, size_t n, uint64_t *out);
+int zk_vec_from_canonical(int field, const uint64_t *canon, size_t n, uint64_t *mont);
+int zk_vec_to_canonical(int field, const uint64_t *mont, size_t n, uint64_t *canon);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,48 @@
+// context.h -- library-internal: status helpers, HIP error capture, per-device scratch, tables.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/zkmle.h"
+
+namespace zk {
+
+void set_last_error(const std::string &s);
+
+#define ZK_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            ::zk::set_last_error(std::string(#call) + ": " + hipGetErrorString(e__));         \
+            return (e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice ||                \
+                    e__ == hipErrorInsufficientDriver) ? ZK_E_NO_DEVICE : ZK_E_HIP;           \
+        }                                                                                     \
+    } while (0)
+
+#define ZK_TRY(expr)                         \
+    do {                                     \
+        int rc__ = (expr);                   \
+        if (rc__ != ZK_OK) return rc__;      \
+    } while (0)
+
+// Fails loudly (ZK_E_NO_DEVICE) when there is no GPU: there is no CPU fallback in this library.
+int require_device();
+// device scratch for reduction partials: at least `bytes` bytes, owned per device, reused
+int scratch(size_t bytes, void **out);
+// pinned host staging for small results (a few field elements)
+int host_staging(size_t bytes, void **out);
+
+inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+inline unsigned ilog2(size_t x) { unsigned k = 0; while (x >>= 1) k++; return k; }
+inline int field_limbs64(int field) { return field == ZK_FQ381 ? 6 : (field >= 0 && field <= 3 ? 4 : -1); }
+
+}  // namespace zk
+
+struct zk_table {
+    int field;
+    size_t len;
+    void *dptr;
+    bool owned;
+};

@@ -1,0 +1,177 @@
+// mle_kernels.cuh -- HIP kernels for the multilinear-extension table operations (gfx950).
+//
+// All kernels stream AoS tables of Montgomery elements (32 B for 4x64-bit fields) with 16-byte
+// vector loads, one element per lane per access, grid-stride; they are HBM-bound by design:
+//   fold:  2 x 32 B read + 32 B write per field multiplication  (96 B / mul)
+// Reference loops restated: polynomials/src/multilinear/evaluation_form.rs:61-106 (fold),
+// :49-57 / :108-163 (element-wise and tensor ops), sumcheck_protocol/src/basic_sumcheck/prover.rs:74-89
+// (half sums).
+#pragma once
+#include "fields.cuh"
+
+namespace zk {
+
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kMaxBlocks = 2048;     // 256 CUs x 8 blocks: grid-stride the rest (guide G11)
+
+// ---- synthetic data: SplitMix64 keyed by (seed, element index, word) -----------------
+ZK_HD uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// element `idx` of the stream `seed`: N/2 pseudo-random u64 words, top limb masked to
+// (bitlen(p) - 1) bits so the value is < p; the words ARE the stored (Montgomery) limbs.
+template <class F> ZK_HD Fe<F> random_element(uint64_t seed, uint64_t idx) {
+    Fe<F> e;
+#pragma unroll
+    for (int k = 0; k < F::N / 2; k++) {
+        uint64_t w = splitmix64(seed ^ splitmix64(idx * (F::N / 2) + k));
+        e.l[2 * k] = (uint32_t)w;
+        e.l[2 * k + 1] = (uint32_t)(w >> 32);
+    }
+    uint32_t top = F::p(F::N - 1);
+    int bits = 32 - __builtin_clz(top);          // bit length of the top limb of p
+    e.l[F::N - 1] &= (bits >= 2) ? ((1u << (bits - 1)) - 1u) : 0u;
+    return e;
+}
+template <class F> __global__ void fill_random_kernel(void *out, size_t len, uint64_t seed, size_t first) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride)
+        fe_store<F>(out, i, random_element<F>(seed, first + i));
+}
+
+// ---- fold: out[i] = y1 + r * (y2 - y1)   evaluation_form.rs:88-89 -----------------------------------
+// `power` = n - 1 - var (:80).  Output index i maps to y1 index j = i with a zero bit inserted
+// at position `power` (the reference's j-walk :98-102), y2 = j | 1<<power (:82).
+template <class F> __global__ void fold_kernel(const void *__restrict__ in, void *__restrict__ out,
+                                              size_t half, unsigned power, Fe<F> r) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t lowmask = ((size_t)1 << power) - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
+        size_t j = ((i & ~lowmask) << 1) | (i & lowmask);
+        Fe<F> y1 = fe_load<F>(in, j);
+        Fe<F> y2 = fe_load<F>(in, j | ((size_t)1 << power));
+        fe_store<F>(out, i, fe_add<F>(y1, fe_mul<F>(r, fe_sub<F>(y2, y1))));
+    }
+}
+
+// ---- reductions ------------------------------------------------------------------------------------
+template <class F> __device__ __forceinline__ Fe<F> wave_reduce_add(Fe<F> v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Fe<F> o;
+#pragma unroll
+        for (int k = 0; k < F::N; k++) o.l[k] = __shfl_down(v.l[k], off, 64);
+        v = fe_add<F>(v, o);
+    }
+    return v;
+}
+// block-wide sum; valid in thread 0.  `sh` holds kBlock/64 elements.
+template <class F> __device__ __forceinline__ Fe<F> block_reduce_add(Fe<F> v, Fe<F> *sh) {
+    v = wave_reduce_add<F>(v);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    Fe<F> tot = fe_zero<F>();
+    if (threadIdx.x == 0) {
+        tot = sh[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) tot = fe_add<F>(tot, sh[w]);
+    }
+    __syncthreads();
+    return tot;
+}
+
+// partial sums of `nseg` equal contiguous segments of the table: partials[seg * gridDim.x + block]
+// (nseg = 1: iter().sum() prover.rs:28 ; nseg = 2: split_polynomial_and_sum_each prover.rs:74-89)
+template <class F> __global__ void segment_sums_kernel(const void *__restrict__ in, size_t seglen, int nseg,
+                                                      void *__restrict__ partials) {
+    __shared__ Fe<F> sh[kBlock / 64];
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (int s = 0; s < nseg; s++) {
+        Fe<F> acc = fe_zero<F>();
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < seglen; i += stride)
+            acc = fe_add<F>(acc, fe_load<F>(in, (size_t)s * seglen + i));
+        Fe<F> tot = block_reduce_add<F>(acc, sh);
+        if (threadIdx.x == 0) fe_store<F>(partials, (size_t)s * gridDim.x + blockIdx.x, tot);
+    }
+}
+// one block: out[s] = sum of partials[s * count .. (s+1) * count)
+template <class F> __global__ void finish_sums_kernel(const void *__restrict__ partials, size_t count, int nseg,
+                                                     void *__restrict__ out) {
+    __shared__ Fe<F> sh[kBlock / 64];
+    for (int s = 0; s < nseg; s++) {
+        Fe<F> acc = fe_zero<F>();
+        for (size_t i = threadIdx.x; i < count; i += blockDim.x)
+            acc = fe_add<F>(acc, fe_load<F>(partials, (size_t)s * count + i));
+        Fe<F> tot = block_reduce_add<F>(acc, sh);
+        if (threadIdx.x == 0) fe_store<F>(out, s, tot);
+    }
+}
+
+// ---- fused sumcheck round: fold variable 0 AND the folded table's two half sums ------------------------
+// (prover.rs:50 of round k+1 fused into prover.rs:61-63 of round k.)  in has 4q elements,
+// out has 2q; lane handles output indices i and i + q: 4 loads, 2 stores, 2 multiplications.
+template <class F> __global__ void fold_half_sums_kernel(const void *__restrict__ in, void *__restrict__ out,
+                                                        size_t q, Fe<F> r, void *__restrict__ partials) {
+    __shared__ Fe<F> sh[kBlock / 64];
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    Fe<F> s0 = fe_zero<F>(), s1 = fe_zero<F>();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
+        Fe<F> a0 = fe_load<F>(in, i), a1 = fe_load<F>(in, i + q);
+        Fe<F> b0 = fe_load<F>(in, i + 2 * q), b1 = fe_load<F>(in, i + 3 * q);
+        Fe<F> o0 = fe_add<F>(a0, fe_mul<F>(r, fe_sub<F>(b0, a0)));
+        Fe<F> o1 = fe_add<F>(a1, fe_mul<F>(r, fe_sub<F>(b1, a1)));
+        fe_store<F>(out, i, o0);
+        fe_store<F>(out, i + q, o1);
+        s0 = fe_add<F>(s0, o0);
+        s1 = fe_add<F>(s1, o1);
+    }
+    Fe<F> t0 = block_reduce_add<F>(s0, sh);
+    Fe<F> t1 = block_reduce_add<F>(s1, sh);
+    if (threadIdx.x == 0) {
+        fe_store<F>(partials, blockIdx.x, t0);
+        fe_store<F>(partials, (size_t)gridDim.x + blockIdx.x, t1);
+    }
+}
+
+// ---- element-wise and tensor operations --------------------------------------------------------------
+enum { OP_SCALAR_MUL = 0, OP_ADD = 1, OP_SUB_SCALAR = 2, OP_TO_CANONICAL_BE = 3, OP_HI_MINUS_LO = 4 };
+
+template <class F, int OP> __global__ void elementwise_kernel(const void *__restrict__ a, const void *__restrict__ b,
+                                                             void *__restrict__ out, size_t len, Fe<F> s) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+        Fe<F> x = fe_load<F>(a, i), o;
+        if (OP == OP_SCALAR_MUL) o = fe_mul<F>(x, s);                         // evaluation_form.rs:53
+        else if (OP == OP_ADD) o = fe_add<F>(x, fe_load<F>(b, i));            // :159
+        else if (OP == OP_SUB_SCALAR) o = fe_sub<F>(x, s);                    // multilinear_kzg.rs:77
+        else if (OP == OP_HI_MINUS_LO) o = fe_sub<F>(fe_load<F>(a, i + len), x);   // multilinear_kzg.rs:172-176
+        else {                                                                // evaluation_form.rs:39
+            Fe<F> c = fe_to_canonical<F>(x);                                  // into_bigint()
+#pragma unroll
+            for (int k = 0; k < F::N; k++) o.l[k] = __builtin_bswap32(c.l[F::N - 1 - k]);   // to_bytes_be()
+        }
+        fe_store<F>(out, i, o);
+    }
+}
+
+// out[b * m + c] = wb[b] (+|*) wc[c]   evaluation_form.rs:116-120 / :136-140 (b-major)
+template <class F, bool MUL> __global__ void tensor_kernel(const void *__restrict__ wb, const void *__restrict__ wc,
+                                                          void *__restrict__ out, size_t m) {
+    size_t total = m * m, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        Fe<F> x = fe_load<F>(wb, i / m), y = fe_load<F>(wc, i % m);
+        fe_store<F>(out, i, MUL ? fe_mul<F>(x, y) : fe_add<F>(x, y));
+    }
+}
+
+inline int grid_for(size_t work) {
+    size_t b = (work + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+}  // namespace zk

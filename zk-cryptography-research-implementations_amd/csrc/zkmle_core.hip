@@ -1,0 +1,388 @@
+// zkmle_core.hip -- C ABI: device context, HBM-resident tables and the MLE operations.
+// Product path only: every compute entry point runs HIP kernels; there is no CPU fallback.
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "context.h"
+#include "mle_kernels.cuh"
+
+namespace zk {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &s) { g_last_error = s; }
+
+struct DeviceScratch {
+    void *dev = nullptr;
+    size_t dev_bytes = 0;
+    void *host = nullptr;
+    size_t host_bytes = 0;
+};
+static std::mutex g_mu;
+static std::vector<DeviceScratch> g_scratch;
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_last_error(std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
+        return ZK_E_NO_DEVICE;
+    }
+    return ZK_OK;
+}
+
+static int current_scratch(DeviceScratch **out) {
+    int dev = 0;
+    ZK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((int)g_scratch.size() <= dev) g_scratch.resize(dev + 1);
+    *out = &g_scratch[dev];
+    return ZK_OK;
+}
+
+int scratch(size_t bytes, void **out) {
+    DeviceScratch *s;
+    ZK_TRY(current_scratch(&s));
+    if (s->dev_bytes < bytes) {
+        if (s->dev) ZK_HIP(hipFree(s->dev));
+        s->dev = nullptr;
+        s->dev_bytes = 0;
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        ZK_HIP(hipMalloc(&s->dev, want));
+        s->dev_bytes = want;
+    }
+    *out = s->dev;
+    return ZK_OK;
+}
+
+int host_staging(size_t bytes, void **out) {
+    DeviceScratch *s;
+    ZK_TRY(current_scratch(&s));
+    if (s->host_bytes < bytes) {
+        if (s->host) ZK_HIP(hipHostFree(s->host));
+        s->host = nullptr;
+        s->host_bytes = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        ZK_HIP(hipHostMalloc(&s->host, want, hipHostMallocDefault));
+        s->host_bytes = want;
+    }
+    *out = s->host;
+    return ZK_OK;
+}
+
+template <class F> static Fe<F> load_host(const uint64_t *src) {
+    Fe<F> e;
+    memcpy(e.l, src, sizeof(uint32_t) * F::N);
+    return e;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+template <int OP> static int elementwise(const zk_table *a, const zk_table *b, const uint64_t *scalar, zk_table *out,
+                                         size_t outlen, void *stream) {
+    ZK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    uint64_t zero[6] = {0, 0, 0, 0, 0, 0};
+    const uint64_t *sc = scalar ? scalar : zero;
+    ZK_DISPATCH_FIELD(a->field, (elementwise_kernel<F, OP><<<grid_for(outlen), kBlock, 0, s>>>(
+                                    a->dptr, b ? b->dptr : nullptr, out->dptr, outlen, load_host<F>(sc))));
+    ZK_HIP(hipGetLastError());
+    out->len = outlen;
+    return ZK_OK;
+}
+extern "C" {
+
+const char *zk_status_message(int status) {
+    switch (status) {
+        case ZK_OK: return "ok";
+        case ZK_E_NOT_POW2: return "Evaluated values must be a power of 2";
+        case ZK_E_LEN_MISMATCH: return "Different polynomial length";
+        case ZK_E_NVARS: return "different number of variables";
+        case ZK_E_NEED_TWO: return "more than one polynomial required for mul operation";
+        case ZK_E_KZG_LEN: return "Polynomial evaluation must match g1 length";
+        case ZK_E_RANGE: return "index out of range";
+        case ZK_E_ARG: return "bad argument";
+        case ZK_E_NOMEM: return "out of memory";
+        case ZK_E_NO_DEVICE: return "no usable HIP device (libzkmle_amd has no CPU fallback)";
+        case ZK_E_HIP: return "HIP runtime error";
+        case ZK_E_NOT_INIT: return "Can't prove without init";
+        default: return "unknown status";
+    }
+}
+const char *zk_last_error(void) { return g_last_error.c_str(); }
+const char *zk_version(void) { return "zkmle_amd 0.1 (gfx950)"; }
+
+int zk_device_count(int *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return ZK_OK;
+}
+int zk_init(int device) {
+    ZK_TRY(require_device());
+    ZK_HIP(hipSetDevice(device));
+    return ZK_OK;
+}
+int zk_field_limbs(int field) {
+    int n = field_limbs64(field);
+    return n < 0 ? ZK_E_ARG : n;
+}
+int zk_device_synchronize(void) {
+    ZK_TRY(require_device());
+    ZK_HIP(hipDeviceSynchronize());
+    return ZK_OK;
+}
+
+// ---- tables ---------------------------------------------------------------------------------------
+int zk_table_alloc(int field, size_t len, zk_table **out) {
+    int limbs = field_limbs64(field);
+    if (limbs < 0 || !out || len == 0) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    void *d = nullptr;
+    ZK_HIP(hipMalloc(&d, len * (size_t)limbs * 8));
+    *out = new zk_table{field, len, d, true};
+    return ZK_OK;
+}
+int zk_table_upload(int field, const uint64_t *host, size_t len, zk_table **out) {
+    if (!host || !out) return ZK_E_ARG;
+    if (!is_pow2(len)) return ZK_E_NOT_POW2;   // MultilinearPolynomial::new, evaluation_form.rs:13
+    ZK_TRY(zk_table_alloc(field, len, out));
+    hipError_t e = hipMemcpy((*out)->dptr, host, len * (size_t)field_limbs64(field) * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        zk_table_free(*out);
+        *out = nullptr;
+        ZK_HIP(e);
+    }
+    return ZK_OK;
+}
+int zk_table_download(const zk_table *t, uint64_t *host) {
+    if (!t || !host) return ZK_E_ARG;
+    ZK_HIP(hipMemcpy(host, t->dptr, t->len * (size_t)field_limbs64(t->field) * 8, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+int zk_table_free(zk_table *t) {
+    if (!t) return ZK_OK;
+    if (t->owned && t->dptr) ZK_HIP(hipFree(t->dptr));
+    delete t;
+    return ZK_OK;
+}
+size_t zk_table_len(const zk_table *t) { return t ? t->len : 0; }
+int zk_table_field(const zk_table *t) { return t ? t->field : ZK_E_ARG; }
+void *zk_table_device_ptr(zk_table *t) { return t ? t->dptr : nullptr; }
+int zk_table_wrap(int field, void *device_ptr, size_t len, zk_table **out) {
+    if (field_limbs64(field) < 0 || !device_ptr || !out || len == 0) return ZK_E_ARG;
+    *out = new zk_table{field, len, device_ptr, false};
+    return ZK_OK;
+}
+int zk_table_clone(const zk_table *t, zk_table **out) {
+    if (!t || !out) return ZK_E_ARG;
+    ZK_TRY(zk_table_alloc(t->field, t->len, out));
+    ZK_HIP(hipMemcpy((*out)->dptr, t->dptr, t->len * (size_t)field_limbs64(t->field) * 8, hipMemcpyDeviceToDevice));
+    return ZK_OK;
+}
+int zk_table_fill_random(zk_table *t, uint64_t seed) {
+    if (!t) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(t->field, (fill_random_kernel<F><<<grid_for(t->len), kBlock>>>(t->dptr, t->len, seed, 0)));
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int zk_host_fill_random(int field, uint64_t seed, size_t first, size_t count, uint64_t *out) {
+    if (!out) return ZK_E_ARG;
+    ZK_DISPATCH_FIELD(field, {
+        for (size_t i = 0; i < count; i++) {
+            Fe<F> e = random_element<F>(seed, first + i);
+            memcpy(out + i * (F::N / 2), e.l, sizeof(uint32_t) * F::N);
+        }
+    });
+    return ZK_OK;
+}
+
+// ---- fold -----------------------------------------------------------------------------------------
+int zk_mle_fold_ptr(int field, const void *d_in, size_t len, size_t var, const uint64_t *value, void *d_out,
+                    void *stream) {
+    if (!d_in || !d_out || !value || field_limbs64(field) < 0) return ZK_E_ARG;
+    if (!is_pow2(len)) return ZK_E_NOT_POW2;
+    unsigned n = ilog2(len);
+    if (len < 2) return ZK_E_NOT_POW2;      // result would be empty: new() asserts (evaluation_form.rs:105 -> :13)
+    if (var + 1 > n) return ZK_E_RANGE;     // power = n - 1 - var underflows (:80)
+    ZK_TRY(require_device());
+    size_t half = len / 2;
+    unsigned power = n - 1 - (unsigned)var;
+    hipStream_t s = (hipStream_t)stream;
+    ZK_DISPATCH_FIELD(field, (fold_kernel<F><<<grid_for(half), kBlock, 0, s>>>(d_in, d_out, half, power, load_host<F>(value))));
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int zk_mle_fold(const zk_table *in, size_t var, const uint64_t *value, zk_table *out, void *stream) {
+    if (!in || !out) return ZK_E_ARG;
+    if (out->field != in->field || out->len < in->len / 2 || out->dptr == in->dptr) return ZK_E_ARG;
+    ZK_TRY(zk_mle_fold_ptr(in->field, in->dptr, in->len, var, value, out->dptr, stream));
+    out->len = in->len / 2;
+    return ZK_OK;
+}
+
+// ---- sums -----------------------------------------------------------------------------------------
+static int sums_impl(const zk_table *t, int nseg, uint64_t *out) {
+    if (!t || !out) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    size_t esz = (size_t)field_limbs64(t->field) * 8;
+    size_t seglen = t->len / nseg;
+    int grid = grid_for(seglen);
+    void *part, *host;
+    ZK_TRY(scratch(esz * ((size_t)grid * nseg + nseg), &part));
+    ZK_TRY(host_staging(esz * nseg, &host));
+    void *res = (char *)part + esz * (size_t)grid * nseg;
+    ZK_DISPATCH_FIELD(t->field, {
+        segment_sums_kernel<F><<<grid, kBlock>>>(t->dptr, seglen, nseg, part);
+        finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, nseg, res);
+    });
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpy(host, res, esz * nseg, hipMemcpyDeviceToHost));
+    memcpy(out, host, esz * nseg);
+    return ZK_OK;
+}
+int zk_mle_sum(const zk_table *t, uint64_t *out) { return sums_impl(t, 1, out); }
+int zk_mle_half_sums(const zk_table *t, uint64_t *out2) {
+    if (!t) return ZK_E_ARG;
+    if (t->len < 2) return ZK_E_ARG;
+    return sums_impl(t, 2, out2);
+}
+
+int zk_mle_fold_half_sums(const zk_table *in, const uint64_t *value, zk_table *out, uint64_t *out2, void *stream) {
+    if (!in || !out || !value || !out2) return ZK_E_ARG;
+    if (out->field != in->field || out->len < in->len / 2 || out->dptr == in->dptr) return ZK_E_ARG;
+    if (!is_pow2(in->len)) return ZK_E_NOT_POW2;
+    if (in->len < 4) return ZK_E_ARG;       // callers finish tables of < 4 entries on the host
+    ZK_TRY(require_device());
+    size_t esz = (size_t)field_limbs64(in->field) * 8;
+    size_t q = in->len / 4;
+    int grid = grid_for(q);
+    void *part, *host;
+    ZK_TRY(scratch(esz * ((size_t)grid * 2 + 2), &part));
+    ZK_TRY(host_staging(esz * 2, &host));
+    void *res = (char *)part + esz * (size_t)grid * 2;
+    hipStream_t s = (hipStream_t)stream;
+    ZK_DISPATCH_FIELD(in->field, {
+        fold_half_sums_kernel<F><<<grid, kBlock, 0, s>>>(in->dptr, out->dptr, q, load_host<F>(value), part);
+        finish_sums_kernel<F><<<1, kBlock, 0, s>>>(part, (size_t)grid, 2, res);
+    });
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(host, res, esz * 2, hipMemcpyDeviceToHost, s));
+    ZK_HIP(hipStreamSynchronize(s));
+    memcpy(out2, host, esz * 2);
+    out->len = in->len / 2;
+    return ZK_OK;
+}
+
+// ---- element-wise / tensor ---------------------------------------------------------------------------
+int zk_mle_scalar_mul(const zk_table *a, const uint64_t *scalar, zk_table *out, void *stream) {
+    if (!a || !scalar || !out || out->field != a->field || out->len < a->len) return ZK_E_ARG;
+    return elementwise<OP_SCALAR_MUL>(a, nullptr, scalar, out, a->len, stream);
+}
+int zk_mle_sub_scalar(const zk_table *a, const uint64_t *scalar, zk_table *out, void *stream) {
+    if (!a || !scalar || !out || out->field != a->field || out->len < a->len) return ZK_E_ARG;
+    return elementwise<OP_SUB_SCALAR>(a, nullptr, scalar, out, a->len, stream);
+}
+int zk_mle_add(const zk_table *a, const zk_table *b, zk_table *out, void *stream) {
+    if (!a || !b || !out || a->field != b->field || out->field != a->field) return ZK_E_ARG;
+    if (a->len != b->len) return ZK_E_LEN_MISMATCH;      // evaluation_form.rs:149-153
+    if (out->len < a->len) return ZK_E_ARG;
+    return elementwise<OP_ADD>(a, b, nullptr, out, a->len, stream);
+}
+static int tensor_impl(const zk_table *wb, const zk_table *wc, zk_table *out, void *stream, bool mul) {
+    if (!wb || !wc || !out || wb->field != wc->field || out->field != wb->field) return ZK_E_ARG;
+    if (wb->len != wc->len) return ZK_E_LEN_MISMATCH;    // :112 / :129-132
+    size_t total = wb->len * wc->len;
+    if (out->len < total) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    if (mul) {
+        ZK_DISPATCH_FIELD(wb->field, (tensor_kernel<F, true><<<grid_for(total), kBlock, 0, s>>>(wb->dptr, wc->dptr, out->dptr, wb->len)));
+    } else {
+        ZK_DISPATCH_FIELD(wb->field, (tensor_kernel<F, false><<<grid_for(total), kBlock, 0, s>>>(wb->dptr, wc->dptr, out->dptr, wb->len)));
+    }
+    ZK_HIP(hipGetLastError());
+    out->len = total;
+    return ZK_OK;
+}
+int zk_mle_tensor_add(const zk_table *wb, const zk_table *wc, zk_table *out, void *stream) {
+    return tensor_impl(wb, wc, out, stream, false);
+}
+int zk_mle_tensor_mul(const zk_table *wb, const zk_table *wc, zk_table *out, void *stream) {
+    return tensor_impl(wb, wc, out, stream, true);
+}
+
+int zk_mle_to_bytes(const zk_table *t, uint8_t *host_out) {
+    if (!t || !host_out) return ZK_E_ARG;
+    zk_table *tmp = nullptr;
+    ZK_TRY(zk_table_alloc(t->field, t->len, &tmp));
+    int rc = elementwise<OP_TO_CANONICAL_BE>(t, nullptr, nullptr, tmp, t->len, nullptr);
+    if (rc == ZK_OK) rc = zk_table_download(tmp, (uint64_t *)host_out);
+    zk_table_free(tmp);
+    return rc;
+}
+
+// ---- evaluate: clone + nvalues folds of variable 0, element 0 (evaluation_form.rs:21-33) ----------------
+int zk_mle_evaluate(const zk_table *t, const uint64_t *values, size_t nvalues, uint64_t *out) {
+    if (!t || !out || (nvalues && !values)) return ZK_E_ARG;
+    if (!is_pow2(t->len)) return ZK_E_NOT_POW2;
+    if (nvalues > ilog2(t->len)) return ZK_E_NOT_POW2;   // folding a 1-entry table: empty Vec -> assert :13
+    ZK_TRY(require_device());
+    int limbs = field_limbs64(t->field);
+    size_t esz = (size_t)limbs * 8;
+    if (nvalues == 0) {
+        ZK_HIP(hipMemcpy(out, t->dptr, esz, hipMemcpyDeviceToHost));
+        return ZK_OK;
+    }
+    // ping-pong between two halves of one scratch allocation (len/2 + len/4 elements)
+    zk_table *a = nullptr, *b = nullptr;
+    ZK_TRY(zk_table_alloc(t->field, t->len / 2, &a));
+    int rc = ZK_OK;
+    if (t->len >= 4) rc = zk_table_alloc(t->field, t->len / 4, &b);
+    const zk_table *cur = t;
+    zk_table *dst = a, *other = b;
+    for (size_t i = 0; i < nvalues && rc == ZK_OK; i++) {
+        dst->len = cur->len / 2;
+        rc = zk_mle_fold_ptr(t->field, cur->dptr, cur->len, 0, values + i * limbs, dst->dptr, nullptr);
+        cur = dst;
+        zk_table *nx = other;
+        other = dst;
+        dst = nx;
+    }
+    if (rc == ZK_OK) {
+        hipError_t e = hipMemcpy(out, cur->dptr, esz, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
+    }
+    zk_table_free(a);
+    zk_table_free(b);
+    return rc;
+}
+
+// ---- stateless host-buffer conveniences ------------------------------------------------------------------
+int zk_host_partial_evaluate(int field, const uint64_t *poly, size_t len, size_t var, const uint64_t *value,
+                             uint64_t *out) {
+    if (!poly || !value || !out) return ZK_E_ARG;
+    zk_table *in = nullptr, *o = nullptr;
+    ZK_TRY(zk_table_upload(field, poly, len, &in));
+    int rc = len >= 2 ? zk_table_alloc(field, len / 2, &o) : ZK_E_NOT_POW2;
+    if (rc == ZK_OK) rc = zk_mle_fold(in, var, value, o, nullptr);
+    if (rc == ZK_OK) rc = zk_table_download(o, out);
+    zk_table_free(in);
+    zk_table_free(o);
+    return rc;
+}
+int zk_host_evaluate(int field, const uint64_t *poly, size_t len, const uint64_t *values, size_t nvalues,
+                     uint64_t *out) {
+    if (!poly || !out) return ZK_E_ARG;
+    zk_table *in = nullptr;
+    ZK_TRY(zk_table_upload(field, poly, len, &in));
+    int rc = zk_mle_evaluate(in, values, nvalues, out);
+    zk_table_free(in);
+    return rc;
+}
+
+}  // extern "C"
