@@ -64,6 +64,36 @@ __global__ void k_copy16(const uint4 *in, uint4 *out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
 }
 
+
+// ---- fold variants (same arithmetic, different launch / memory shapes) ---------------------------
+template <class F> __device__ __forceinline__ zk::Fe<F> nt_load(const void *base, size_t idx) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(base) + idx * (F::N / 4);
+    zk::Fe<F> r;
+#pragma unroll
+    for (int k = 0; k < F::N / 4; k++) {
+        uint4 v;
+        v.x = __builtin_nontemporal_load(&p[k].x); v.y = __builtin_nontemporal_load(&p[k].y);
+        v.z = __builtin_nontemporal_load(&p[k].z); v.w = __builtin_nontemporal_load(&p[k].w);
+        r.l[4 * k + 0] = v.x; r.l[4 * k + 1] = v.y; r.l[4 * k + 2] = v.z; r.l[4 * k + 3] = v.w;
+    }
+    return r;
+}
+template <class F, int EPT, bool NT> __global__ void k_fold_v(const void *__restrict__ in, void *__restrict__ out, size_t half, zk::Fe<F> r) {
+    // EPT elements per thread, strided by half/EPT so every access stays coalesced
+    size_t chunk = half / EPT;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chunk) return;
+    zk::Fe<F> lo[EPT], hi[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        lo[e] = NT ? nt_load<F>(in, i + e * chunk) : zk::fe_load<F>(in, i + e * chunk);
+        hi[e] = NT ? nt_load<F>(in, i + e * chunk + half) : zk::fe_load<F>(in, i + e * chunk + half);
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+        zk::fe_store<F>(out, i + e * chunk, zk::fe_add<F>(lo[e], zk::fe_mul<F>(r, zk::fe_sub<F>(hi[e], lo[e]))));
+}
+
 template <class Fn> static float time_ms(Fn fn, int reps) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -141,6 +171,20 @@ int main(int argc, char **argv) {
             printf("{\"kernel\": \"fold_fr381_2p24\", \"grid\": %d, \"ms\": %.4f, \"GBps\": %.1f, \"field_mul_per_s\": %.4e}\n", grid, ms,
                    96.0 * half / (ms * 1e-3) / 1e9, half / (ms * 1e-3));
             fflush(stdout);
+        }
+
+        {
+            zk::Fe<zk::Fr381> r = zk::random_element<zk::Fr381>(5, 5);
+#define RUN_V(EPT, NT, BS)                                                                                  \
+            {                                                                                               \
+                int grid = (int)((half / EPT + BS - 1) / BS);                                               \
+                float ms = time_ms([&] { k_fold_v<zk::Fr381, EPT, NT><<<grid, BS>>>(in, out, half, r); }, 20); \
+                printf("{\"kernel\": \"fold_v\", \"ept\": %d, \"nt\": %d, \"block\": %d, \"grid\": %d, \"ms\": %.4f, \"GBps\": %.1f}\n", EPT, (int)NT, BS, grid, ms, 96.0 * half / (ms * 1e-3) / 1e9); \
+                fflush(stdout);                                                                             \
+            }
+            RUN_V(1, false, 256) RUN_V(1, false, 512) RUN_V(1, false, 1024) RUN_V(1, false, 128) RUN_V(1, false, 64)
+            RUN_V(2, false, 256) RUN_V(4, false, 256) RUN_V(2, false, 128) RUN_V(2, false, 512)
+            RUN_V(1, true, 256) RUN_V(2, true, 256)
         }
         float ms = time_ms([&] { k_copy16<<<2048, 256>>>((const uint4 *)in, (uint4 *)out, half * 2); }, 10);
         printf("{\"kernel\": \"copy16\", \"ms\": %.4f, \"GBps\": %.1f}\n", ms, 2.0 * 32 * half / (ms * 1e-3) / 1e9);

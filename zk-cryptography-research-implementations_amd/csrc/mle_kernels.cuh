@@ -12,7 +12,11 @@
 namespace zk {
 
 constexpr int kBlock = 256;          // 4 waves of 64
-constexpr int kMaxBlocks = 2048;     // 256 CUs x 8 blocks: grid-stride the rest (guide G11)
+// Streaming kernels launch one element per lane (measured on MI355X, profiles/microbench_r1.jsonl:
+// 2^23-output fold 5.28 TB/s at 32768 blocks vs 4.67 TB/s capped at 2048); reductions keep a
+// bounded grid because they emit one partial per block.
+constexpr int kMaxBlocks = 1 << 16;
+constexpr int kMaxReduceBlocks = 4096;
 
 // ---- synthetic data: SplitMix64 keyed by (seed, element index, word) -----------------
 ZK_HD uint64_t splitmix64(uint64_t x) {
@@ -167,11 +171,12 @@ template <class F, bool MUL> __global__ void tensor_kernel(const void *__restric
     }
 }
 
-inline int grid_for(size_t work) {
+inline int grid_for(size_t work, int cap = kMaxBlocks) {
     size_t b = (work + kBlock - 1) / kBlock;
     if (b < 1) b = 1;
-    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+    if (b > (size_t)cap) b = cap;
     return (int)b;
 }
+inline int reduce_grid_for(size_t work) { return grid_for(work, kMaxReduceBlocks); }
 
 }  // namespace zk

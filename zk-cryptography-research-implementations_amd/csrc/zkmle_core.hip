@@ -231,7 +231,7 @@ static int sums_impl(const zk_table *t, int nseg, uint64_t *out) {
     ZK_TRY(require_device());
     size_t esz = (size_t)field_limbs64(t->field) * 8;
     size_t seglen = t->len / nseg;
-    int grid = grid_for(seglen);
+    int grid = reduce_grid_for(seglen);
     void *part, *host;
     ZK_TRY(scratch(esz * ((size_t)grid * nseg + nseg), &part));
     ZK_TRY(host_staging(esz * nseg, &host));
@@ -260,7 +260,7 @@ int zk_mle_fold_half_sums(const zk_table *in, const uint64_t *value, zk_table *o
     ZK_TRY(require_device());
     size_t esz = (size_t)field_limbs64(in->field) * 8;
     size_t q = in->len / 4;
-    int grid = grid_for(q);
+    int grid = reduce_grid_for(q);
     void *part, *host;
     ZK_TRY(scratch(esz * ((size_t)grid * 2 + 2), &part));
     ZK_TRY(host_staging(esz * 2, &host));
