@@ -110,6 +110,48 @@ int zk_fe_from_le_bytes_mod_order(int field, const uint8_t *bytes, size_t n, uin
 int zk_vec_from_canonical(int field, const uint64_t *canon, size_t n, uint64_t *mont);
 int zk_vec_to_canonical(int field, const uint64_t *mont, size_t n, uint64_t *canon);
 
+/* ---- Fiat-Shamir transcript (host; transcripts/src/fiat_shamir/fiat_shamir_transcript.rs:5-43) ---- */
+typedef struct zk_transcript zk_transcript;
+int zk_transcript_new(zk_transcript **out);                                        /* Transcript::new :12 */
+int zk_transcript_free(zk_transcript *t);
+int zk_transcript_append(zk_transcript *t, const uint8_t *data, size_t n);         /* append :22 */
+int zk_transcript_sample(zk_transcript *t, uint8_t out32[32]);                     /* sample_random_challenge :29 */
+int zk_transcript_challenge(zk_transcript *t, int field, uint64_t *out);           /* random_challenge_as_field_element :38 */
+int zk_keccak256(const uint8_t *data, size_t n, uint8_t out32[32]);
+
+/* ---- univariate helpers (host; polynomials/src/univariate/dense_univariate.rs) ------------------ */
+int zk_uni_evaluate(int field, const uint64_t *coeffs, size_t n, const uint64_t *x, uint64_t *out);        /* :57 */
+int zk_uni_lagrange_interpolate(int field, const uint64_t *xs, const uint64_t *ys, size_t n, uint64_t *out); /* :74 */
+
+/* ---- basic sumcheck (sumcheck_protocol/src/basic_sumcheck) ------------------------------------- */
+/* Prover::init + Prover::prove  prover.rs:22-71.  The table stays in HBM; per round one fused
+ * fold + half-sums kernel; the host owns the transcript.  round_polys: nvars*2 elements
+ * (SumcheckProof.round_univariate_polynomials); challenges (nvars) is diagnostic, may be NULL. */
+int zk_sumcheck_basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys,
+                            uint64_t *challenges);
+/* Verifier::verify  verifier.rs:23-71 (its final `evaluate` is the same GPU fold); *ok = 1 / 0 */
+int zk_sumcheck_basic_verify(const zk_table *table, const uint64_t *claimed_sum,
+                             const uint64_t *round_polys, size_t nrounds, int *ok);
+
+/* ---- composed polynomials + GKR sumcheck ----------------------------------------------------------
+ * A SumPolynomial (polynomials/src/composed/sum_polynomial.rs:7-9) of `nprod` ProductPolynomials
+ * (product_polynomial.rs:6-8) with `nfac` MLEs each is passed as tables[p * nfac + f].
+ * SumPolynomial::new / ProductPolynomial::new assert equal variable counts (ZK_E_NVARS). */
+int zk_sumpoly_evaluate(const zk_table *const *tables, size_t nprod, size_t nfac,
+                        const uint64_t *values, size_t nvalues, uint64_t *out);    /* sum_polynomial.rs:30 */
+int zk_sumpoly_reduce(const zk_table *const *tables, size_t nprod, size_t nfac, zk_table *out); /* :57 add_polynomials_element_wise */
+/* generate_round_univariate sumcheck_gkr_protocol.rs:113-143 ; out: nfac+1 evaluations at 0..nfac */
+int zk_sumpoly_round_evals(const zk_table *const *tables, size_t nprod, size_t nfac, uint64_t *out);
+/* prove  sumcheck_gkr_protocol.rs:24-67.  round_coeffs: nvars*(nfac+1) coefficients, challenges: nvars.
+ * The caller's tables are not modified (the reference clones, :33). */
+int zk_sumcheck_gkr_prove(const zk_table *const *tables, size_t nprod, size_t nfac,
+                          const uint64_t *claimed_sum, zk_transcript *t, uint64_t *round_coeffs,
+                          uint64_t *challenges);
+/* verify :69-105 (host only: O(rounds) field operations) */
+int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_t *round_coeffs,
+                           size_t nrounds, size_t ncoef, zk_transcript *t, uint64_t *challenges,
+                           uint64_t *last_claimed_sum, int *ok);
+
 #ifdef __cplusplus
 }
 #endif

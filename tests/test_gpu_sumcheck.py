@@ -1,0 +1,191 @@
+"""GPU parity: basic sumcheck and GKR sumcheck provers (proof bytes identical to the oracle's),
+mirroring sumcheck_protocol/src/basic_sumcheck/protocol.rs and gkr_sumcheck/sumcheck_gkr_protocol.rs tests."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as G
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+FID = {"bn254_fq": 2, "bls12_381_fr": 0}
+
+
+@pytest.fixture(scope="module")
+def zk():
+    zk = G.import_package()
+    from zkmle_amd import _lib
+    _lib.check(zk.lib().zk_init(0))
+    return zk
+
+
+def rand_table(zk, field, n, seed):
+    t = np.zeros((n, zk.limbs(field)), np.uint64)
+    assert zk.lib().zk_host_fill_random(field, seed, 0, n, t.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+    return t
+
+
+def test_prover_init_claimed_sums(zk, ref_kats):
+    for k in ref_kats["basic_sumcheck_claimed_sum"]:          # prover.rs:99-107, protocol.rs:10-26
+        f = FID[k["field"]]
+        prover = zk.Prover.init(f, zk.from_ints(f, k["table"]))
+        assert zk.to_ints(f, prover.initial_claimed_sum) == [k["expect"]]
+        assert prover.is_initialized is True
+        assert prover.initial_polynomial.to_ints() == k["table"]
+    with pytest.raises(zk.ReferencePanic, match="Can't prove without init"):
+        zk.Prover().prove()
+
+
+def test_basic_sumcheck_reference_roundtrips(zk, ref_kats):
+    for k in ref_kats["basic_sumcheck_roundtrip"]:            # protocol.rs:28-116
+        f = FID[k["field"]]
+        if "table" in k:
+            table = zk.from_ints(f, k["table"])
+        else:                                                 # vec![Fr::from(3); 1 << 20]  protocol.rs:42-44 (full size here)
+            table = np.tile(zk.from_ints(f, [k["table_constant"]]), (1 << k["log_len"], 1))
+        prover = zk.Prover.init(f, table)
+        proof = prover.prove()
+        assert zk.Verifier.init().verify(proof) is True, k["src"]
+        if len(table) <= (1 << 12):
+            cs, rp, ch = O.sumcheck_basic_prove(f, table)
+            assert np.array_equal(proof.initial_claimed_sum, cs)
+            assert np.array_equal(proof.round_univariate_polynomials, rp)
+            assert np.array_equal(prover.challenges, ch)
+        bad = zk.sumcheck.SumcheckProof(proof.initial_polynomial, proof.initial_claimed_sum,
+                                        proof.round_univariate_polynomials.copy())
+        bad.round_univariate_polynomials[0, 0, 0] ^= np.uint64(1)
+        assert zk.Verifier.init().verify(bad) is False
+
+
+def test_basic_sumcheck_derived_vectors(zk, derived_kats):
+    for d in derived_kats["basic_sumcheck"]:
+        f = FID[d["field"]]
+        prover = zk.Prover.init(f, zk.from_ints(f, d["table"]))
+        proof = prover.prove()
+        assert zk.to_ints(f, proof.initial_claimed_sum) == [int(d["claimed"], 16)]
+        for got, exp in zip(proof.round_univariate_polynomials, d["rounds"]):
+            assert zk.to_ints(f, got) == [int(x, 16) for x in exp]
+        assert zk.to_ints(f, prover.challenges)[: len(d["challenges"])] == [int(x, 16) for x in d["challenges"]]
+
+
+@pytest.mark.parametrize("field", [0, 2, 3])
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 7, 12, 16])
+def test_basic_sumcheck_random_vs_oracle(zk, field, logn):
+    table = rand_table(zk, field, 1 << logn, 1000 + logn)
+    prover = zk.Prover.init(field, table)
+    proof = prover.prove()
+    cs, rp, ch = O.sumcheck_basic_prove(field, table)
+    assert np.array_equal(proof.initial_claimed_sum, cs)
+    assert np.array_equal(proof.round_univariate_polynomials.reshape(rp.shape), rp)
+    assert np.array_equal(prover.challenges.reshape(ch.shape), ch)
+    assert zk.Verifier.init().verify(proof) is True
+
+
+def test_basic_sumcheck_config2_2p20_random(zk):
+    """BASELINE config 2 size (20 variables, random table): proof equals the oracle's"""
+    field, logn = 0, 20
+    table = rand_table(zk, field, 1 << logn, 0x5EED0002)
+    prover = zk.Prover.init(field, table)
+    proof = prover.prove()
+    cs, rp, ch = O.sumcheck_basic_prove(field, table)
+    assert np.array_equal(proof.initial_claimed_sum, cs)
+    assert np.array_equal(proof.round_univariate_polynomials, rp)
+    assert zk.Verifier.init().verify(proof) is True
+
+
+def mk_sum(zk, f, products):
+    MP = zk.MultilinearPolynomial
+    return zk.SumPolynomial([zk.ProductPolynomial([MP(f, t) for t in prod]) for prod in products])
+
+
+def test_composed_polynomial_reference_kats(zk, ref_kats):
+    MP = zk.MultilinearPolynomial
+    k = ref_kats["product_poly"]
+    f = FID[k["field"]]
+    pp = zk.ProductPolynomial([MP.from_ints(f, t) for t in k["polys"]])
+    assert zk.to_ints(f, pp.evaluate(zk.from_ints(f, k["evaluate"]["values"]))) == [k["evaluate"]["expect"]]
+    pe = k["partial_evaluate"]
+    assert [p.to_ints() for p in pp.partial_evaluate(pe["var"], zk.from_ints(f, [pe["value"]])[0])] == pe["expect"]
+    assert pp.multiply_polynomials_element_wise().to_ints() == k["multiply_element_wise"]
+    assert pp.degree() == k["degree"]
+    with pytest.raises(zk.ReferencePanic, match="different number of variables"):
+        zk.ProductPolynomial([MP.from_ints(f, t) for t in k["new_panics"]["polys"]])
+    s = ref_kats["sum_poly"]
+    sp = zk.SumPolynomial([zk.ProductPolynomial([MP.from_ints(f, t) for t in prod]) for prod in s["products"]])
+    assert zk.to_ints(f, sp.evaluate(zk.from_ints(f, s["evaluate"]["values"]))) == [s["evaluate"]["expect"]]
+    assert sp.add_polynomials_element_wise().to_ints() == s["add_element_wise"]
+    assert sp.degree() == s["degree"] and sp.number_of_variables() == s["number_of_variables"]
+    pe = s["partial_evaluate"]
+    folded = sp.partial_evaluate(pe["var"], zk.from_ints(f, [pe["value"]])[0])
+    assert [[p.to_ints() for p in pp_.polynomials] for pp_ in folded.product_polynomials] == pe["expect"]
+    with pytest.raises(zk.ReferencePanic, match="different number of variables"):   # sum_polynomial.rs:101-113
+        zk.SumPolynomial([zk.ProductPolynomial([MP.from_ints(f, [0, 2])]), zk.ProductPolynomial([MP.from_ints(f, [0, 0, 0, 3])])])
+    with pytest.raises(zk.ReferencePanic):
+        zk.SumPolynomial([pp]).add_polynomials_element_wise()
+
+
+def test_gkr_round_univariate_and_roundtrip(zk, ref_kats, derived_kats):
+    for k in ref_kats["gkr_round_univariate"]:               # sumcheck_gkr_protocol.rs:163-186
+        f = FID[k["field"]]
+        sp = mk_sum(zk, f, [[zk.from_ints(f, t) for t in prod] for prod in k["products"]])
+        assert zk.to_ints(f, zk.sumcheck.generate_round_univariate(sp)) == k["expect"]
+    for k in ref_kats["gkr_sumcheck_roundtrip"]:             # :188-212
+        f = FID[k["field"]]
+        sp = mk_sum(zk, f, [[zk.from_ints(f, t) for t in prod] for prod in k["products"]])
+        result = zk.sumcheck.prove(sp, zk.from_ints(f, [k["claimed_sum"]])[0], zk.Transcript.new())
+        verified = zk.sumcheck.verify(result, zk.Transcript.new(), f)
+        assert verified.is_proof_valid is True
+        assert np.array_equal(verified.random_challenges, result.random_challenges)
+        assert np.array_equal(sp.evaluate(result.random_challenges), verified.last_claimed_sum)
+    d = derived_kats["gkr_sumcheck"]
+    f = FID[d["field"]]
+    sp = mk_sum(zk, f, [[zk.from_ints(f, t) for t in prod] for prod in d["products"]])
+    result = zk.sumcheck.prove(sp, zk.from_ints(f, [d["claimed"]])[0], zk.Transcript.new())
+    assert [zk.to_ints(f, r) for r in result.round_univariate_polynomials] == [[int(x, 16) for x in r] for r in d["coeffs"]]
+    assert zk.to_ints(f, result.random_challenges) == [int(x, 16) for x in d["challenges"]]
+    bad = zk.sumcheck.verify(zk.sumcheck.SumcheckProverProof(zk.from_ints(f, [13])[0], result.round_univariate_polynomials,
+                                                            result.random_challenges), zk.Transcript.new(), f)
+    assert bad.is_proof_valid is False
+
+
+@pytest.mark.parametrize("field", [0, 2])
+@pytest.mark.parametrize("shape", [(2, 2, 1), (2, 2, 2), (2, 2, 5), (2, 2, 11), (3, 2, 6), (2, 3, 6), (1, 2, 4), (4, 3, 3), (2, 1, 4)])
+def test_gkr_sumcheck_random_vs_oracle(zk, field, shape):
+    nprod, nfac, logn = shape
+    n = 1 << logn
+    tabs = np.stack([np.stack([rand_table(zk, field, n, 50 * p + f + logn) for f in range(nfac)]) for p in range(nprod)])
+    sp = mk_sum(zk, field, tabs)
+    assert np.array_equal(zk.sumcheck.generate_round_univariate(sp), O.gkr_round_univariate(field, tabs)) or nprod < 2 or nfac < 2
+    if nprod >= 2 and nfac >= 2:
+        red = O.sumpoly_reduce(field, tabs)
+        assert np.array_equal(sp.add_polynomials_element_wise().evaluated_values, red)
+        claimed = O.vec_sum(field, red)
+    else:
+        claimed = rand_table(zk, field, 1, 5)[0]
+    if nprod >= 2 and nfac >= 2:
+        t_gpu, t_cpu = zk.Transcript(), O.Transcript()
+        t_gpu.append(b"prefix")
+        t_cpu.append(b"prefix")
+        result = zk.sumcheck.prove(sp, claimed, t_gpu)
+        co, ch = O.sumcheck_gkr_prove(field, tabs, claimed, t_cpu)
+        assert np.array_equal(result.round_univariate_polynomials, co)
+        assert np.array_equal(result.random_challenges, ch)
+        assert t_gpu.sample_random_challenge() == t_cpu.sample_random_challenge()   # transcripts stay in lock-step
+        # inputs untouched (the reference clones, :33)
+        assert np.array_equal(sp.product_polynomials[0].polynomials[0].evaluated_values, tabs[0, 0])
+        tv = zk.Transcript()
+        tv.append(b"prefix")
+        v = zk.sumcheck.verify(result, tv, field)
+        assert v.is_proof_valid and np.array_equal(v.last_claimed_sum, sp.evaluate(ch))
+
+
+def test_gkr_sumcheck_large_2p20(zk):
+    """4 tables of 2^20 (f(b,c) of a layer with 2^10 wires): proof equals the oracle's"""
+    field, n = 2, 1 << 16
+    tabs = np.stack([np.stack([rand_table(zk, field, n, 70 + 2 * p + f) for f in range(2)]) for p in range(2)])
+    sp = mk_sum(zk, field, tabs)
+    claimed = O.vec_sum(field, O.sumpoly_reduce(field, tabs))
+    result = zk.sumcheck.prove(sp, claimed, zk.Transcript())
+    co, ch = O.sumcheck_gkr_prove(field, tabs, claimed, O.Transcript())
+    assert np.array_equal(result.round_univariate_polynomials, co) and np.array_equal(result.random_challenges, ch)

@@ -12,6 +12,8 @@ operations raise.  (The directory name contains '-', so import it with
 from . import _lib
 from ._lib import FR381, FQ381, BN254_FQ, BN254_FR, ZkError, ReferencePanic, lib, library_path  # noqa: F401
 from .mle import MultilinearPolynomial, from_ints, to_ints, limbs  # noqa: F401
+from . import sumcheck  # noqa: F401
+from .sumcheck import Transcript, ProductPolynomial, SumPolynomial, Prover, Verifier  # noqa: F401
 
 __all__ = ["MultilinearPolynomial", "FR381", "FQ381", "BN254_FQ", "BN254_FR", "ZkError", "ReferencePanic",
            "from_ints", "to_ints", "limbs", "lib", "library_path"]

@@ -1,0 +1,42 @@
+// univariate.h -- host-side dense univariate helpers for the sumcheck control path.
+// Mirrors polynomials/src/univariate/dense_univariate.rs: evaluate :57-68, lagrange_interpolate :74-98
+// (lagrange_basis :101-126).  O(d^2) on d+1 <= 4 points per round: negligible, host only.
+#pragma once
+#include <vector>
+
+#include "fields.cuh"
+
+namespace zk {
+
+template <class F> inline Fe<F> uni_evaluate(const std::vector<Fe<F>> &c, const Fe<F> &x) {
+    Fe<F> result = fe_zero<F>(), power = fe_one<F>();
+    for (const Fe<F> &coef : c) {
+        result = fe_add<F>(result, fe_mul<F>(coef, power));
+        power = fe_mul<F>(power, x);
+    }
+    return result;
+}
+
+// n points -> n coefficients (leading zeros kept: the numerator always has n terms)
+template <class F> inline std::vector<Fe<F>> lagrange_interpolate(const std::vector<Fe<F>> &xs, const std::vector<Fe<F>> &ys) {
+    size_t n = xs.size();
+    std::vector<Fe<F>> out(n, fe_zero<F>());
+    for (size_t i = 0; i < n; i++) {
+        std::vector<Fe<F>> num{fe_one<F>()};
+        for (size_t k = 0; k < n; k++) {
+            if (fe_eq<F>(xs[k], xs[i])) continue;              // compares values, as the reference does (:112)
+            std::vector<Fe<F>> nxt(num.size() + 1, fe_zero<F>());
+            Fe<F> nx = fe_neg<F>(xs[k]);
+            for (size_t d = 0; d < num.size(); d++) {          // times (x - x_k)
+                nxt[d] = fe_add<F>(nxt[d], fe_mul<F>(num[d], nx));
+                nxt[d + 1] = fe_add<F>(nxt[d + 1], num[d]);
+            }
+            num.swap(nxt);
+        }
+        Fe<F> scale = fe_mul<F>(ys[i], fe_inv<F>(uni_evaluate<F>(num, xs[i])));
+        for (size_t d = 0; d < num.size(); d++) out[d] = fe_add<F>(out[d], fe_mul<F>(scale, num[d]));
+    }
+    return out;
+}
+
+}  // namespace zk

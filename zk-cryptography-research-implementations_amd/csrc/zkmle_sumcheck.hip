@@ -1,0 +1,396 @@
+// zkmle_sumcheck.hip -- C ABI: transcript, basic sumcheck prover/verifier, SumPolynomial kernels and
+// the GKR sumcheck prover/verifier.  Tables stay in HBM; the host runs only the O(rounds)
+// control path (Keccak transcript, 3-point interpolation).
+#include <string.h>
+
+#include <vector>
+
+#include "context.h"
+#include "sumcheck_kernels.cuh"
+#include "transcript.h"
+#include "univariate.h"
+
+using namespace zk;
+
+namespace {
+
+template <class F> Fe<F> load_el(const uint64_t *src) {
+    Fe<F> e;
+    memcpy(e.l, src, 4 * F::N);
+    return e;
+}
+template <class F> void store_el(uint64_t *dst, const Fe<F> &e) { memcpy(dst, e.l, 4 * F::N); }
+
+struct DevBuf {   // RAII device allocation
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { ZK_HIP(hipMalloc(&p, bytes ? bytes : 16)); return ZK_OK; }
+};
+
+// absorb convert_to_bytes(table) (evaluation_form.rs:35-43) chunk by chunk:
+// GPU converts Montgomery -> canonical big-endian, host absorbs into the sponge
+template <class F> int absorb_table(Transcript &t, const void *dptr, size_t len) {
+    const size_t esz = 4 * F::N;
+    const size_t chunk = (size_t)1 << 21;   // elements per chunk (64 MiB for 32-byte elements)
+    size_t cl = len < chunk ? len : chunk;
+    DevBuf tmp;
+    ZK_TRY(tmp.alloc(cl * esz));
+    std::vector<uint8_t> host(cl * esz);
+    for (size_t off = 0; off < len; off += chunk) {
+        size_t n = len - off < chunk ? len - off : chunk;
+        elementwise_kernel<F, OP_TO_CANONICAL_BE><<<grid_for(n), kBlock>>>((const char *)dptr + off * esz, nullptr, tmp.p, n, fe_zero<F>());
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpy(host.data(), tmp.p, n * esz, hipMemcpyDeviceToHost));
+        t.append(host.data(), n * esz);
+    }
+    return ZK_OK;
+}
+
+template <class F> int download_elems(const void *d, size_t n, Fe<F> *out) {
+    ZK_HIP(hipMemcpy(out, d, n * 4 * F::N, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+
+// ---- basic sumcheck prover: prover.rs:22-71 ----------------------------------------------------------
+template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys, uint64_t *challenges) {
+    const size_t esz = 4 * F::N, L64 = F::N / 2;
+    size_t len = table->len;
+    unsigned nvars = ilog2(len);
+    Transcript tr;
+    ZK_TRY(absorb_table<F>(tr, table->dptr, len));                     // :38-39
+    // working buffers: len/2 and len/4 elements, plus reduction partials
+    DevBuf bufA, bufB;
+    ZK_TRY(bufA.alloc((len / 2) * esz));
+    ZK_TRY(bufB.alloc((len / 4) * esz));
+    void *part;
+    ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * 2 + 2), &part));
+    Fe<F> sums[2];
+    if (len == 1) {                                                    // zero variables: sum = the entry, no rounds
+        ZK_TRY(download_elems<F>(table->dptr, 1, sums));
+        store_el<F>(claimed_sum, sums[0]);
+        tr.append_be<F>(sums[0]);
+        return ZK_OK;
+    }
+    // round-0 half sums (split_polynomial_and_sum_each :74-89); claimed sum = their sum (:28)
+    {
+        size_t seg = len / 2;
+        int grid = reduce_grid_for(seg);
+        void *res = (char *)part + esz * (size_t)grid * 2;
+        segment_sums_kernel<F><<<grid, kBlock>>>(table->dptr, seg, 2, part);
+        finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, 2, res);
+        ZK_HIP(hipGetLastError());
+        ZK_TRY(download_elems<F>(res, 2, sums));
+    }
+    Fe<F> claimed = fe_add<F>(sums[0], sums[1]);
+    store_el<F>(claimed_sum, claimed);
+    tr.append_be<F>(claimed);                                          // :40-41
+    const void *cur = table->dptr;
+    void *dst = bufA.p, *other = bufB.p;
+    size_t cl = len;
+    for (unsigned round = 0; round < nvars; round++) {                 // :46
+        store_el<F>(round_polys + (size_t)(2 * round) * L64, sums[0]); // :50-53
+        store_el<F>(round_polys + (size_t)(2 * round + 1) * L64, sums[1]);
+        tr.append_be<F>(sums[0]);                                      // :54-55 (a 2-entry table, big-endian)
+        tr.append_be<F>(sums[1]);
+        Fe<F> r = tr.random_challenge_as_field_element<F>();           // :58
+        if (challenges) store_el<F>(challenges + (size_t)round * L64, r);
+        if (cl >= 4) {                                                 // :61-63 fused with the next round's :50
+            size_t q = cl / 4;
+            int grid = reduce_grid_for(q);
+            void *res = (char *)part + esz * (size_t)grid * 2;
+            fold_half_sums_kernel<F><<<grid, kBlock>>>(cur, dst, q, r, part);
+            finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, 2, res);
+            ZK_HIP(hipGetLastError());
+            ZK_TRY(download_elems<F>(res, 2, sums));
+        } else {                                                       // 2 entries -> 1: nothing left to sum
+            fold_kernel<F><<<1, kBlock>>>(cur, dst, 1, 0, r);
+            ZK_HIP(hipGetLastError());
+        }
+        cur = dst;
+        void *nx = other;
+        other = dst;
+        dst = nx;
+        cl /= 2;
+    }
+    ZK_HIP(hipDeviceSynchronize());
+    return ZK_OK;
+}
+
+// ---- basic sumcheck verifier: verifier.rs:23-71 -------------------------------------------------------
+template <class F> int basic_verify(const zk_table *table, const uint64_t *claimed_sum, const uint64_t *round_polys,
+                                    size_t nrounds, int *ok) {
+    const size_t L64 = F::N / 2;
+    *ok = 0;
+    if (nrounds != ilog2(table->len)) return ZK_OK;                    // :26-30
+    Transcript tr;
+    ZK_TRY(absorb_table<F>(tr, table->dptr, table->len));              // :34-35
+    Fe<F> cur = load_el<F>(claimed_sum);
+    tr.append_be<F>(cur);                                              // :36-37
+    std::vector<uint64_t> chal(nrounds * L64 + L64);
+    for (size_t i = 0; i < nrounds; i++) {                             // :47
+        Fe<F> e0 = load_el<F>(round_polys + (2 * i) * L64), e1 = load_el<F>(round_polys + (2 * i + 1) * L64);
+        // evaluating a 2-entry table at 0 / 1 returns its entries (:51-52)
+        if (!fe_eq<F>(fe_add<F>(e0, e1), cur)) return ZK_OK;           // :53-56
+        tr.append_be<F>(e0);                                           // :58-59
+        tr.append_be<F>(e1);
+        Fe<F> c = tr.random_challenge_as_field_element<F>();           // :61
+        store_el<F>(chal.data() + i * L64, c);
+        cur = fe_add<F>(e0, fe_mul<F>(c, fe_sub<F>(e1, e0)));          // :64
+    }
+    uint64_t fin[6];
+    ZK_TRY(zk_mle_evaluate(table, chal.data(), nrounds, fin));         // :67 -- the GPU fold chain
+    *ok = fe_eq<F>(load_el<F>(fin), cur) ? 1 : 0;                      // :70
+    return ZK_OK;
+}
+
+// ---- SumPolynomial helpers ------------------------------------------------------------------------------
+int check_sumpoly(const zk_table *const *tables, size_t nprod, size_t nfac) {
+    if (!tables || nprod == 0 || nfac == 0) return ZK_E_ARG;
+    if (nprod > (size_t)kMaxProducts || nfac > (size_t)kMaxFactors) return ZK_E_ARG;
+    for (size_t k = 0; k < nprod * nfac; k++) {
+        if (!tables[k]) return ZK_E_ARG;
+        if (tables[k]->field != tables[0]->field) return ZK_E_ARG;
+        if (!is_pow2(tables[k]->len)) return ZK_E_NOT_POW2;
+        if (tables[k]->len != tables[0]->len) return ZK_E_NVARS;      // product_polynomial.rs:16-21, sum_polynomial.rs:17-23
+    }
+    return ZK_OK;
+}
+
+template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t half, void *part, int grid) {
+    if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock>>>(tabs, nprod, half, part);
+    else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock>>>(tabs, nprod, half, part);
+    else round_evals_kernel<F, 3><<<grid, kBlock>>>(tabs, nprod, half, part);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t q, const Fe<F> &r, void *part, int grid) {
+    if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock>>>(tabs, nprod, q, r, part);
+    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock>>>(tabs, nprod, q, r, part);
+    else fold_round_evals_kernel<F, 3><<<grid, kBlock>>>(tabs, nprod, q, r, part);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class F> int round_evals(const zk_table *const *tables, size_t nprod, size_t nfac, uint64_t *out) {
+    const size_t esz = 4 * F::N;
+    size_t len = tables[0]->len;
+    if (len < 2) return ZK_E_NOT_POW2;
+    SumPolyTables tabs{};
+    for (size_t k = 0; k < nprod * nfac; k++) tabs.in[k] = tables[k]->dptr;
+    size_t half = len / 2;
+    int grid = reduce_grid_for(half);
+    size_t npts = nfac + 1;
+    void *part;
+    ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
+    void *res = (char *)part + esz * (size_t)grid * npts;
+    ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
+    finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, (int)npts, res);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpy(out, res, esz * npts, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+
+// ---- GKR sumcheck prover: sumcheck_gkr_protocol.rs:24-67 --------------------------------------------------
+template <class F> int gkr_sumcheck_prove(const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *claimed_sum,
+                                          Transcript &tr, uint64_t *round_coeffs, uint64_t *challenges) {
+    const size_t esz = 4 * F::N, L64 = F::N / 2;
+    const size_t ntab = nprod * nfac, npts = nfac + 1;                 // degree() = polynomials.len() (:114, sum_polynomial.rs:88)
+    size_t len = tables[0]->len;
+    unsigned nvars = ilog2(len);                                       // :29
+    tr.append_be<F>(load_el<F>(claimed_sum));                          // :35
+    if (nvars == 0) return ZK_OK;
+    DevBuf bufA, bufB;
+    ZK_TRY(bufA.alloc(ntab * (len / 2) * esz));
+    ZK_TRY(bufB.alloc(ntab * (len / 4) * esz));
+    void *part;
+    ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
+    std::vector<Fe<F>> xs(npts), evals(npts);
+    for (size_t i = 0; i < npts; i++) xs[i] = fe_from_u64<F>(i);       // :46-48
+    SumPolyTables tabs{};
+    for (size_t k = 0; k < ntab; k++) tabs.in[k] = tables[k]->dptr;
+    // round 0 evaluations
+    {
+        size_t half = len / 2;
+        int grid = reduce_grid_for(half);
+        void *res = (char *)part + esz * (size_t)grid * npts;
+        ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
+        finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, (int)npts, res);
+        ZK_HIP(hipGetLastError());
+        ZK_TRY(download_elems<F>(res, npts, evals.data()));
+    }
+    char *dst = (char *)bufA.p, *other = (char *)bufB.p;
+    size_t cl = len;
+    for (unsigned round = 0; round < nvars; round++) {                 // :37
+        std::vector<Fe<F>> co = lagrange_interpolate<F>(xs, evals);    // :49-50
+        for (size_t i = 0; i < npts; i++) {
+            tr.append_le<F>(co[i]);                                    // :52 little-endian coefficients
+            store_el<F>(round_coeffs + ((size_t)round * npts + i) * L64, co[i]);
+        }
+        Fe<F> r = tr.random_challenge_as_field_element<F>();           // :55
+        store_el<F>(challenges + (size_t)round * L64, r);              // :59
+        size_t ol = cl / 2;
+        for (size_t k = 0; k < ntab; k++) tabs.out[k] = dst + k * ol * esz;
+        if (cl >= 4) {                                                 // :57 fused with next round's :41
+            size_t q = cl / 4;
+            int grid = reduce_grid_for(q);
+            void *res = (char *)part + esz * (size_t)grid * npts;
+            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, r, part, grid)));
+            finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, (int)npts, res);
+            ZK_HIP(hipGetLastError());
+            ZK_TRY(download_elems<F>(res, npts, evals.data()));
+        } else {
+            fold_all_kernel<F><<<1, kBlock>>>(tabs, (int)ntab, 1, r);
+            ZK_HIP(hipGetLastError());
+        }
+        for (size_t k = 0; k < ntab; k++) tabs.in[k] = tabs.out[k];
+        char *nx = other;
+        other = dst;
+        dst = nx;
+        cl = ol;
+    }
+    ZK_HIP(hipDeviceSynchronize());
+    return ZK_OK;
+}
+
+template <class F> int gkr_sumcheck_verify(const uint64_t *claimed_sum, const uint64_t *round_coeffs, size_t nrounds, size_t ncoef,
+                                           Transcript &tr, uint64_t *challenges, uint64_t *last, int *ok) {
+    const size_t L64 = F::N / 2;
+    Fe<F> cur = load_el<F>(claimed_sum);
+    tr.append_be<F>(cur);                                              // :73
+    *ok = 1;
+    for (size_t r = 0; r < nrounds; r++) {                             // :78
+        std::vector<Fe<F>> c(ncoef);
+        for (size_t i = 0; i < ncoef; i++) c[i] = load_el<F>(round_coeffs + (r * ncoef + i) * L64);
+        Fe<F> e0 = uni_evaluate<F>(c, fe_zero<F>()), e1 = uni_evaluate<F>(c, fe_one<F>());   // :81-82
+        if (!fe_eq<F>(fe_add<F>(e0, e1), cur)) { *ok = 0; break; }     // :84-90
+        for (size_t i = 0; i < ncoef; i++) tr.append_le<F>(c[i]);      // :92
+        Fe<F> ch = tr.random_challenge_as_field_element<F>();          // :94
+        cur = uni_evaluate<F>(c, ch);                                  // :96
+        store_el<F>(challenges + r * L64, ch);
+    }
+    store_el<F>(last, cur);
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zk_transcript_new(zk_transcript **out) {
+    if (!out) return ZK_E_ARG;
+    *out = new zk_transcript();
+    return ZK_OK;
+}
+int zk_transcript_free(zk_transcript *t) { delete t; return ZK_OK; }
+int zk_transcript_append(zk_transcript *t, const uint8_t *data, size_t n) {
+    if (!t || (!data && n)) return ZK_E_ARG;
+    t->t.append(data, n);
+    return ZK_OK;
+}
+int zk_transcript_sample(zk_transcript *t, uint8_t out32[32]) {
+    if (!t || !out32) return ZK_E_ARG;
+    t->t.sample_random_challenge(out32);
+    return ZK_OK;
+}
+int zk_transcript_challenge(zk_transcript *t, int field, uint64_t *out) {
+    if (!t || !out) return ZK_E_ARG;
+    ZK_DISPATCH_FIELD(field, store_el<F>(out, t->t.random_challenge_as_field_element<F>()));
+    return ZK_OK;
+}
+int zk_keccak256(const uint8_t *data, size_t n, uint8_t out32[32]) {
+    if ((!data && n) || !out32) return ZK_E_ARG;
+    Keccak256 h;
+    h.update(data, n);
+    h.finalize_copy(out32);
+    return ZK_OK;
+}
+
+int zk_uni_evaluate(int field, const uint64_t *coeffs, size_t n, const uint64_t *x, uint64_t *out) {
+    if ((!coeffs && n) || !x || !out) return ZK_E_ARG;
+    ZK_DISPATCH_FIELD(field, {
+        std::vector<Fe<F>> c(n);
+        for (size_t i = 0; i < n; i++) c[i] = load_el<F>(coeffs + i * (F::N / 2));
+        store_el<F>(out, uni_evaluate<F>(c, load_el<F>(x)));
+    });
+    return ZK_OK;
+}
+int zk_uni_lagrange_interpolate(int field, const uint64_t *xs, const uint64_t *ys, size_t n, uint64_t *out) {
+    if (!xs || !ys || !out || n == 0) return ZK_E_ARG;
+    ZK_DISPATCH_FIELD(field, {
+        std::vector<Fe<F>> x(n), y(n);
+        for (size_t i = 0; i < n; i++) { x[i] = load_el<F>(xs + i * (F::N / 2)); y[i] = load_el<F>(ys + i * (F::N / 2)); }
+        std::vector<Fe<F>> c = lagrange_interpolate<F>(x, y);
+        for (size_t i = 0; i < n; i++) store_el<F>(out + i * (F::N / 2), c[i]);
+    });
+    return ZK_OK;
+}
+
+int zk_sumcheck_basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys, uint64_t *challenges) {
+    if (!table || !claimed_sum || !round_polys) return ZK_E_ARG;
+    if (!is_pow2(table->len)) return ZK_E_NOT_POW2;      // Prover::init -> MultilinearPolynomial::new (prover.rs:23)
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(table->field, return basic_prove<F>(table, claimed_sum, round_polys, challenges));
+    return ZK_OK;
+}
+int zk_sumcheck_basic_verify(const zk_table *table, const uint64_t *claimed_sum, const uint64_t *round_polys, size_t nrounds, int *ok) {
+    if (!table || !claimed_sum || (!round_polys && nrounds) || !ok) return ZK_E_ARG;
+    if (!is_pow2(table->len)) return ZK_E_NOT_POW2;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(table->field, return basic_verify<F>(table, claimed_sum, round_polys, nrounds, ok));
+    return ZK_OK;
+}
+
+int zk_sumpoly_round_evals(const zk_table *const *tables, size_t nprod, size_t nfac, uint64_t *out) {
+    ZK_TRY(check_sumpoly(tables, nprod, nfac));
+    if (!out) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(tables[0]->field, return round_evals<F>(tables, nprod, nfac, out));
+    return ZK_OK;
+}
+int zk_sumpoly_reduce(const zk_table *const *tables, size_t nprod, size_t nfac, zk_table *out) {
+    ZK_TRY(check_sumpoly(tables, nprod, nfac));
+    if (!out || out->field != tables[0]->field || out->len < tables[0]->len) return ZK_E_ARG;
+    if (nprod < 2 || nfac < 2) return ZK_E_NEED_TWO;     // sum_polynomial.rs:58-61 / product_polynomial.rs:59-62
+    ZK_TRY(require_device());
+    SumPolyTables tabs{};
+    for (size_t k = 0; k < nprod * nfac; k++) tabs.in[k] = tables[k]->dptr;
+    size_t len = tables[0]->len;
+    ZK_DISPATCH_FIELD(tables[0]->field, (sumpoly_reduce_kernel<F><<<grid_for(len), kBlock>>>(tabs, (int)nprod, (int)nfac, len, out->dptr)));
+    ZK_HIP(hipGetLastError());
+    out->len = len;
+    return ZK_OK;
+}
+int zk_sumpoly_evaluate(const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *values, size_t nvalues, uint64_t *out) {
+    ZK_TRY(check_sumpoly(tables, nprod, nfac));
+    if (!out) return ZK_E_ARG;
+    ZK_DISPATCH_FIELD(tables[0]->field, {
+        Fe<F> result = fe_zero<F>();                      // sum_polynomial.rs:31
+        for (size_t p = 0; p < nprod; p++) {
+            Fe<F> prod = fe_one<F>();                     // product_polynomial.rs:27
+            for (size_t f = 0; f < nfac; f++) {
+                uint64_t e[6];
+                ZK_TRY(zk_mle_evaluate(tables[p * nfac + f], values, nvalues, e));
+                prod = fe_mul<F>(prod, load_el<F>(e));
+            }
+            result = fe_add<F>(result, prod);
+        }
+        store_el<F>(out, result);
+    });
+    return ZK_OK;
+}
+int zk_sumcheck_gkr_prove(const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *claimed_sum,
+                          zk_transcript *t, uint64_t *round_coeffs, uint64_t *challenges) {
+    ZK_TRY(check_sumpoly(tables, nprod, nfac));
+    if (!claimed_sum || !t || !round_coeffs || !challenges) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(tables[0]->field, return gkr_sumcheck_prove<F>(tables, nprod, nfac, claimed_sum, t->t, round_coeffs, challenges));
+    return ZK_OK;
+}
+int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_t *round_coeffs, size_t nrounds, size_t ncoef,
+                           zk_transcript *t, uint64_t *challenges, uint64_t *last_claimed_sum, int *ok) {
+    if (!claimed_sum || (!round_coeffs && nrounds) || !t || !challenges || !last_claimed_sum || !ok) return ZK_E_ARG;
+    ZK_DISPATCH_FIELD(field, return gkr_sumcheck_verify<F>(claimed_sum, round_coeffs, nrounds, ncoef, t->t, challenges, last_claimed_sum, ok));
+    return ZK_OK;
+}
+
+}  // extern "C"
