@@ -156,7 +156,15 @@ def test_gkr_sumcheck_random_vs_oracle(zk, field, shape):
     n = 1 << logn
     tabs = np.stack([np.stack([rand_table(zk, field, n, 50 * p + f + logn) for f in range(nfac)]) for p in range(nprod)])
     sp = mk_sum(zk, field, tabs)
-    assert np.array_equal(zk.sumcheck.generate_round_univariate(sp), O.gkr_round_univariate(field, tabs)) or nprod < 2 or nfac < 2
+    if nprod < 2 or nfac < 2:      # add_polynomials_element_wise asserts "> 1" (sum_polynomial.rs:58-61, product_polynomial.rs:59-62)
+        with pytest.raises(O.OraclePanic):
+            O.gkr_round_univariate(field, tabs)
+        with pytest.raises(zk.ReferencePanic):
+            zk.sumcheck.generate_round_univariate(sp)
+        with pytest.raises(zk.ReferencePanic):
+            zk.sumcheck.prove(sp, rand_table(zk, field, 1, 5)[0], zk.Transcript())
+        return
+    assert np.array_equal(zk.sumcheck.generate_round_univariate(sp), O.gkr_round_univariate(field, tabs))
     if nprod >= 2 and nfac >= 2:
         red = O.sumpoly_reduce(field, tabs)
         assert np.array_equal(sp.add_polynomials_element_wise().evaluated_values, red)

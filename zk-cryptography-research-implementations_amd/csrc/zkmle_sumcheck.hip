@@ -343,6 +343,8 @@ int zk_sumcheck_basic_verify(const zk_table *table, const uint64_t *claimed_sum,
 int zk_sumpoly_round_evals(const zk_table *const *tables, size_t nprod, size_t nfac, uint64_t *out) {
     ZK_TRY(check_sumpoly(tables, nprod, nfac));
     if (!out) return ZK_E_ARG;
+    // the reference reduces with add_polynomials_element_wise (:134), which asserts > 1 (sum_polynomial.rs:58-61)
+    if (nprod < 2 || nfac < 2) return ZK_E_NEED_TWO;
     ZK_TRY(require_device());
     ZK_DISPATCH_FIELD(tables[0]->field, return round_evals<F>(tables, nprod, nfac, out));
     return ZK_OK;
@@ -382,6 +384,7 @@ int zk_sumcheck_gkr_prove(const zk_table *const *tables, size_t nprod, size_t nf
                           zk_transcript *t, uint64_t *round_coeffs, uint64_t *challenges) {
     ZK_TRY(check_sumpoly(tables, nprod, nfac));
     if (!claimed_sum || !t || !round_coeffs || !challenges) return ZK_E_ARG;
+    if ((nprod < 2 || nfac < 2) && tables[0]->len > 1) return ZK_E_NEED_TWO;   // first round's generate_round_univariate panics
     ZK_TRY(require_device());
     ZK_DISPATCH_FIELD(tables[0]->field, return gkr_sumcheck_prove<F>(tables, nprod, nfac, claimed_sum, t->t, round_coeffs, challenges));
     return ZK_OK;
