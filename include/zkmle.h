@@ -152,6 +152,35 @@ int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_
                            size_t nrounds, size_t ncoef, zk_transcript *t, uint64_t *challenges,
                            uint64_t *last_claimed_sum, int *ok);
 
+/* ---- layered circuit + GKR prover (circuit/src/arithmetic_circuit.rs, gkr/src/gkr_protocol.rs) ----
+ * Gate :9-15 (op 0 = Add, 1 = Mul); a circuit is `nlayers` layers (layer 0 = output layer), its
+ * gates concatenated in `gates` with per-layer counts.  The reference ties width to depth: layer i
+ * reads a 2^(i+1)-entry layer (:166-178); other shapes hit its asserts (ZK_E_NVARS / ZK_E_NOT_POW2). */
+typedef struct { uint64_t left, right, out, op; } zk_gate;
+size_t zk_num_of_layer_variables(size_t layer_index);                               /* :166 */
+size_t zk_wiring_index(size_t layer_index, size_t a, size_t b, size_t c);            /* convert_to_binary_and_to_decimal :180 */
+size_t zk_circuit_eval_size(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, size_t ninputs);
+/* Circuit::evaluate :65-109 ; layer_sizes[nlayers+1], evals = layer 0 .. inputs concatenated */
+int zk_circuit_evaluate(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers,
+                        const uint64_t *inputs, size_t ninputs, size_t *layer_sizes, uint64_t *evals);
+/* add_i_and_mul_i_mle :126-163 : dense wiring predicates, built in HBM */
+int zk_circuit_add_mul_mle(int field, const zk_gate *layer_gates, size_t ngates, size_t layer_index,
+                           zk_table **add_i, zk_table **mul_i);
+/* gkr_protocol::prove  gkr_protocol.rs:26-143.  Flattened Proof (:17-23):
+ *   circuit_output[*output_len]; claimed_sum[1]; layer_claims[nlayers] (each layer's
+ *   SumcheckProverProof.claimed_sum); coeffs: per layer rounds(L)*3 coefficients, rounds(L)=2(L+1);
+ *   challenges: per layer rounds(L); wb_evals / wc_evals [nlayers-1]. */
+size_t zk_gkr_rounds(size_t layer_index);
+int zk_gkr_prove(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers,
+                 const uint64_t *inputs, size_t ninputs, uint64_t *circuit_output, size_t *output_len,
+                 uint64_t *claimed_sum, uint64_t *layer_claims, uint64_t *coeffs, uint64_t *challenges,
+                 uint64_t *wb_evals, uint64_t *wc_evals);
+/* gkr_protocol::verify :146-236 ; *ok = 1 / 0 */
+int zk_gkr_verify(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers,
+                  const uint64_t *inputs, size_t ninputs, const uint64_t *circuit_output, size_t output_len,
+                  const uint64_t *layer_claims, const uint64_t *coeffs, const uint64_t *wb_evals,
+                  const uint64_t *wc_evals, int *ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,8 @@ from ._lib import FR381, FQ381, BN254_FQ, BN254_FR, ZkError, ReferencePanic, lib
 from .mle import MultilinearPolynomial, from_ints, to_ints, limbs  # noqa: F401
 from . import sumcheck  # noqa: F401
 from .sumcheck import Transcript, ProductPolynomial, SumPolynomial, Prover, Verifier  # noqa: F401
+from . import gkr  # noqa: F401
+from .gkr import Circuit, Gate, Layer, Operator  # noqa: F401
 
 __all__ = ["MultilinearPolynomial", "FR381", "FQ381", "BN254_FQ", "BN254_FR", "ZkError", "ReferencePanic",
            "from_ints", "to_ints", "limbs", "lib", "library_path"]

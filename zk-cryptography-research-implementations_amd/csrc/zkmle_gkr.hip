@@ -1,0 +1,352 @@
+// zkmle_gkr.hip -- C ABI: layered circuit, dense wiring predicates and the GKR prover / verifier.
+// Host mirror of circuit/src/arithmetic_circuit.rs, gkr/src/utils.rs and gkr/src/gkr_protocol.rs;
+// every table-sized step (wiring-predicate folds, alpha/beta combination, outer sum / product of W,
+// the sumcheck itself, W evaluations) runs on the GPU through the table API.
+#include <string.h>
+
+#include <memory>
+#include <vector>
+
+#include "context.h"
+#include "sumcheck_kernels.cuh"
+#include "transcript.h"
+
+using namespace zk;
+
+namespace {
+
+struct TableDeleter { void operator()(zk_table *t) const { zk_table_free(t); } };
+using TablePtr = std::unique_ptr<zk_table, TableDeleter>;
+
+template <class F> Fe<F> load_el(const uint64_t *src) { Fe<F> e; memcpy(e.l, src, 4 * F::N); return e; }
+template <class F> void store_el(uint64_t *dst, const Fe<F> &e) { memcpy(dst, e.l, 4 * F::N); }
+
+int alloc_table(int field, size_t len, TablePtr &out) {
+    zk_table *t = nullptr;
+    ZK_TRY(zk_table_alloc(field, len, &t));
+    out.reset(t);
+    return ZK_OK;
+}
+int upload_table(int field, const uint64_t *host, size_t len, TablePtr &out) {
+    zk_table *t = nullptr;
+    ZK_TRY(zk_table_upload(field, host, len, &t));
+    out.reset(t);
+    return ZK_OK;
+}
+
+// format!("{:0>width$b}") arithmetic_circuit.rs:198-200 : at least `width` digits, never truncated
+size_t padded_bits(size_t v, size_t width) {
+    size_t nb = 1;
+    while ((v >> nb) != 0) nb++;
+    return nb > width ? nb : width;
+}
+
+size_t layer_len(const zk_gate *g, size_t n) {   // :73-80 max output index + 1 (0 gates -> 1)
+    size_t mx = 0;
+    for (size_t i = 0; i < n; i++) if (g[i].out > mx) mx = g[i].out;
+    return mx + 1;
+}
+
+// fold `src` by variable 0 with vals[0..k) in turn (utils.rs:38-56 chains); result in `out`
+int fold_chain(const zk_table *src, const uint64_t *vals, size_t k, int limbs, TablePtr &out) {
+    const zk_table *cur = src;
+    TablePtr a, b;
+    for (size_t i = 0; i < k; i++) {
+        if (cur->len < 2) return ZK_E_NOT_POW2;
+        TablePtr nx;
+        ZK_TRY(alloc_table(src->field, cur->len / 2, nx));
+        ZK_TRY(zk_mle_fold(cur, 0, vals + i * limbs, nx.get(), nullptr));
+        a = std::move(b);
+        b = std::move(nx);
+        cur = b.get();
+    }
+    if (k == 0) {
+        zk_table *c = nullptr;
+        ZK_TRY(zk_table_clone(src, &c));
+        out.reset(c);
+    } else {
+        out = std::move(b);
+    }
+    return ZK_OK;
+}
+
+// compute_new_add_i_mul_i utils.rs:23-68 for one predicate: alpha * fold(x, rb) + beta * fold(x, rc)
+int alpha_beta_fold(const zk_table *abc, const uint64_t *alpha, const uint64_t *beta, const uint64_t *rb, const uint64_t *rc,
+                    size_t k, int limbs, TablePtr &out) {
+    if (k == 0) return ZK_E_RANGE;                       // rb_values[0] :38
+    TablePtr frb, frc;
+    ZK_TRY(fold_chain(abc, rb, k, limbs, frb));
+    ZK_TRY(fold_chain(abc, rc, k, limbs, frc));
+    ZK_TRY(zk_mle_scalar_mul(frb.get(), alpha, frb.get(), nullptr));      // :58-59 (in place: element-wise)
+    ZK_TRY(zk_mle_scalar_mul(frc.get(), beta, frc.get(), nullptr));
+    ZK_TRY(alloc_table(abc->field, frb->len, out));
+    ZK_TRY(zk_mle_add(frb.get(), frc.get(), out.get(), nullptr));
+    return ZK_OK;
+}
+
+struct CircuitEval {
+    std::vector<size_t> goff, eoff, lsz;
+    std::vector<uint64_t> evals;
+};
+
+template <class F> int circuit_evaluate(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *inputs,
+                                        size_t ninputs, CircuitEval &ce) {
+    const size_t L64 = F::N / 2;
+    ce.goff.assign(nlayers + 1, 0);
+    ce.eoff.assign(nlayers + 2, 0);
+    ce.lsz.assign(nlayers + 1, 0);
+    for (size_t l = 0; l < nlayers; l++) ce.goff[l + 1] = ce.goff[l] + gate_counts[l];
+    for (size_t l = 0; l < nlayers; l++) ce.lsz[l] = layer_len(gates + ce.goff[l], gate_counts[l]);
+    ce.lsz[nlayers] = ninputs;
+    for (size_t l = 0; l <= nlayers; l++) ce.eoff[l + 1] = ce.eoff[l] + ce.lsz[l];
+    ce.evals.assign(ce.eoff[nlayers + 1] * L64, 0);
+    memcpy(ce.evals.data() + ce.eoff[nlayers] * L64, inputs, ninputs * L64 * 8);      // :69
+    for (size_t l = nlayers; l-- > 0;) {                                               // :72 layers.iter().rev()
+        const uint64_t *cur = ce.evals.data() + ce.eoff[l + 1] * L64;
+        uint64_t *res = ce.evals.data() + ce.eoff[l] * L64;
+        for (size_t k = 0; k < gate_counts[l]; k++) {                                  // :86
+            const zk_gate &g = gates[ce.goff[l] + k];
+            if (g.left >= ce.lsz[l + 1] || g.right >= ce.lsz[l + 1]) return ZK_E_RANGE;
+            Fe<F> a = load_el<F>(cur + g.left * L64), b = load_el<F>(cur + g.right * L64);
+            Fe<F> v = g.op == 0 ? fe_add<F>(a, b) : fe_mul<F>(a, b);                   // :90-93
+            store_el<F>(res + g.out * L64, fe_add<F>(load_el<F>(res + g.out * L64), v));   // :96 +=
+        }
+    }
+    return ZK_OK;
+}
+
+template <class F> int add_mul_mle(const zk_gate *g, size_t ngates, size_t layer_index, TablePtr &add_i, TablePtr &mul_i) {
+    size_t n = (size_t)1 << zk_num_of_layer_variables(layer_index);
+    ZK_TRY(alloc_table(F::ID, n, add_i));
+    ZK_TRY(alloc_table(F::ID, n, mul_i));
+    ZK_HIP(hipMemsetAsync(add_i->dptr, 0, n * 4 * F::N, nullptr));                     // vec![F::zero(); 2^vars] :133-134
+    ZK_HIP(hipMemsetAsync(mul_i->dptr, 0, n * 4 * F::N, nullptr));
+    std::vector<uint64_t> pa, pm;
+    for (size_t k = 0; k < ngates; k++) {
+        size_t pos = zk_wiring_index(layer_index, g[k].out, g[k].left, g[k].right);   // :139-155
+        if (pos >= n) return ZK_E_RANGE;
+        (g[k].op == 0 ? pa : pm).push_back(pos);
+    }
+    for (int w = 0; w < 2; w++) {
+        std::vector<uint64_t> &pos = w ? pm : pa;
+        if (pos.empty()) continue;
+        void *dpos;
+        ZK_TRY(scratch(pos.size() * 8, &dpos));
+        ZK_HIP(hipMemcpy(dpos, pos.data(), pos.size() * 8, hipMemcpyHostToDevice));
+        scatter_one_kernel<F><<<grid_for(pos.size()), kBlock>>>((w ? mul_i : add_i)->dptr, (const uint64_t *)dpos, pos.size());
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipDeviceSynchronize());
+    }
+    return ZK_OK;
+}
+
+// compute_fbc_polynomial utils.rs:8-21 : [add_i_bc, W(b)+W(c), mul_i_bc, W(b)*W(c)]
+int build_fbc(TablePtr &add_bc, TablePtr &mul_bc, const zk_table *w, TablePtr &add_w, TablePtr &mul_w) {
+    if (w->len * w->len != add_bc->len) return ZK_E_NVARS;                            // ProductPolynomial::new product_polynomial.rs:16-21
+    ZK_TRY(alloc_table(w->field, w->len * w->len, add_w));
+    ZK_TRY(alloc_table(w->field, w->len * w->len, mul_w));
+    ZK_TRY(zk_mle_tensor_add(w, w, add_w.get(), nullptr));
+    ZK_TRY(zk_mle_tensor_mul(w, w, mul_w.get(), nullptr));
+    return ZK_OK;
+}
+
+template <class F> int derive_bc(const zk_gate *layer_gates, size_t ngates, size_t L, const uint64_t *ra, const uint64_t *alpha,
+                                 const uint64_t *beta, const uint64_t *rb, const uint64_t *rc, size_t nr, TablePtr &add_bc,
+                                 TablePtr &mul_bc) {
+    const int limbs = F::N / 2;
+    TablePtr add_abc, mul_abc;
+    ZK_TRY((add_mul_mle<F>(layer_gates, ngates, L, add_abc, mul_abc)));               // gkr_protocol.rs:58
+    if (L == 0) {                                                                     // :60-72
+        ZK_TRY(alloc_table(F::ID, add_abc->len / 2, add_bc));
+        ZK_TRY(alloc_table(F::ID, mul_abc->len / 2, mul_bc));
+        ZK_TRY(zk_mle_fold(add_abc.get(), 0, ra, add_bc.get(), nullptr));
+        ZK_TRY(zk_mle_fold(mul_abc.get(), 0, ra, mul_bc.get(), nullptr));
+    } else {                                                                          // :73-82
+        ZK_TRY(alpha_beta_fold(add_abc.get(), alpha, beta, rb, rc, nr, limbs, add_bc));
+        ZK_TRY(alpha_beta_fold(mul_abc.get(), alpha, beta, rb, rc, nr, limbs, mul_bc));
+    }
+    return ZK_OK;
+}
+
+template <class F> int gkr_prove(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *inputs, size_t ninputs,
+                                 uint64_t *circuit_output, size_t *output_len, uint64_t *claimed_sum, uint64_t *layer_claims,
+                                 uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals) {
+    const size_t L64 = F::N / 2;
+    CircuitEval ce;
+    ZK_TRY((circuit_evaluate<F>(gates, gate_counts, nlayers, inputs, ninputs, ce)));  // :27
+    *output_len = ce.lsz[0];
+    memcpy(circuit_output, ce.evals.data(), ce.lsz[0] * L64 * 8);
+    zk_transcript tr;
+    // w0, padded [x] -> [x, 0]  :39-47
+    std::vector<uint64_t> w0(ce.evals.begin(), ce.evals.begin() + ce.lsz[0] * L64);
+    if (ce.lsz[0] == 1) w0.resize(2 * L64, 0);
+    size_t w0len = w0.size() / L64;
+    TablePtr w0t;
+    ZK_TRY(upload_table(F::ID, w0.data(), w0len, w0t));                               // new(): pow2 assert
+    {
+        std::vector<uint8_t> bytes(w0len * 8 * L64);
+        ZK_TRY(zk_mle_to_bytes(w0t.get(), bytes.data()));
+        tr.t.append(bytes.data(), bytes.size());                                     // :49
+    }
+    uint64_t ra[6], claim[6], alpha[6] = {0}, beta[6] = {0};
+    store_el<F>(ra, tr.t.random_challenge_as_field_element<F>());                    // :50
+    ZK_TRY(zk_mle_evaluate(w0t.get(), ra, 1, claim));                                // :51
+    std::vector<uint64_t> rb, rc;
+    size_t nr = 0, coff = 0, choff = 0;
+    for (size_t L = 0; L < nlayers; L++) {                                           // :57
+        TablePtr add_bc, mul_bc, add_w, mul_w, w;
+        ZK_TRY((derive_bc<F>(gates + ce.goff[L], gate_counts[L], L, ra, alpha, beta, rb.data(), rc.data(), nr, add_bc, mul_bc)));
+        ZK_TRY(upload_table(F::ID, ce.evals.data() + ce.eoff[L + 1] * L64, ce.lsz[L + 1], w));   // :88-89 w_i_polynomial
+        ZK_TRY(build_fbc(add_bc, mul_bc, w.get(), add_w, mul_w));                    // :95
+        size_t bclen = add_bc->len, rounds = ilog2(bclen);
+        memcpy(layer_claims + L * L64, claim, L64 * 8);
+        const zk_table *tabs[4] = {add_bc.get(), add_w.get(), mul_bc.get(), mul_w.get()};
+        uint64_t *lco = coeffs + coff * L64, *lch = challenges + choff * L64;
+        ZK_TRY(zk_sumcheck_gkr_prove(tabs, 2, 2, claim, &tr, lco, lch));             // :99
+        if (L + 1 < nlayers) {                                                       // :109
+            size_t mid = rounds / 2;                                                 // :120 / utils.rs:75
+            uint64_t wbe[6], wce[6];
+            ZK_TRY(zk_mle_evaluate(w.get(), lch, mid, wbe));                         // utils.rs:78
+            ZK_TRY(zk_mle_evaluate(w.get(), lch + mid * L64, rounds - mid, wce));    // :79
+            memcpy(wb_evals + L * L64, wbe, L64 * 8);                                // :116-117
+            memcpy(wc_evals + L * L64, wce, L64 * 8);
+            rb.assign(lch, lch + mid * L64);                                         // :121-123
+            rc.assign(lch + mid * L64, lch + rounds * L64);
+            nr = mid;
+            tr.t.append_be<F>(load_el<F>(wbe));                                      // :125
+            Fe<F> a = tr.t.random_challenge_as_field_element<F>();
+            tr.t.append_be<F>(load_el<F>(wce));                                      // :128
+            Fe<F> b = tr.t.random_challenge_as_field_element<F>();
+            store_el<F>(alpha, a);
+            store_el<F>(beta, b);
+            store_el<F>(claim, fe_add<F>(fe_mul<F>(a, load_el<F>(wbe)), fe_mul<F>(b, load_el<F>(wce))));   // :132
+        }
+        coff += rounds * 3;
+        choff += rounds;
+    }
+    memcpy(claimed_sum, claim, L64 * 8);
+    return ZK_OK;
+}
+
+template <class F> int gkr_verify(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *inputs, size_t ninputs,
+                                  const uint64_t *circuit_output, size_t output_len, const uint64_t *layer_claims, const uint64_t *coeffs,
+                                  const uint64_t *wb_evals, const uint64_t *wc_evals, int *ok) {
+    const size_t L64 = F::N / 2;
+    *ok = 0;
+    zk_transcript tr;
+    std::vector<uint64_t> w0(circuit_output, circuit_output + output_len * L64);      // :153-159
+    if (output_len == 1) w0.resize(2 * L64, 0);
+    TablePtr w0t;
+    ZK_TRY(upload_table(F::ID, w0.data(), w0.size() / L64, w0t));
+    {
+        std::vector<uint8_t> bytes(w0.size() * 8);
+        ZK_TRY(zk_mle_to_bytes(w0t.get(), bytes.data()));
+        tr.t.append(bytes.data(), bytes.size());                                     // :161
+    }
+    uint64_t ra[6], claim[6], alpha[6] = {0}, beta[6] = {0};
+    store_el<F>(ra, tr.t.random_challenge_as_field_element<F>());                    // :162
+    ZK_TRY(zk_mle_evaluate(w0t.get(), ra, 1, claim));                                // :164
+    std::vector<uint64_t> prev;
+    size_t goff = 0, coff = 0;
+    for (size_t L = 0; L < nlayers; L++) {                                           // :166
+        if (memcmp(claim, layer_claims + L * L64, L64 * 8) != 0) return ZK_OK;       // :167-169
+        size_t rounds = zk_gkr_rounds(L), mid = rounds / 2;
+        std::vector<uint64_t> ch(rounds * L64);
+        uint64_t last[6];
+        int sok = 0;
+        ZK_TRY(zk_sumcheck_gkr_verify(F::ID, layer_claims + L * L64, coeffs + coff * L64, rounds, 3, &tr, ch.data(), last, &sok));   // :172
+        if (!sok) return ZK_OK;                                                      // :174-176
+        uint64_t wbe[6], wce[6];
+        if (L + 1 < nlayers) {                                                       // :183-187
+            memcpy(wbe, wb_evals + L * L64, L64 * 8);
+            memcpy(wce, wc_evals + L * L64, L64 * 8);
+        } else {                                                                     // :188-194 the verifier's own inputs
+            TablePtr in;
+            ZK_TRY(upload_table(F::ID, inputs, ninputs, in));
+            ZK_TRY(zk_mle_evaluate(in.get(), ch.data(), mid, wbe));
+            ZK_TRY(zk_mle_evaluate(in.get(), ch.data() + mid * L64, rounds - mid, wce));
+        }
+        TablePtr add_bc, mul_bc;
+        size_t k = prev.size() / L64 / 2;
+        ZK_TRY((derive_bc<F>(gates + goff, gate_counts[L], L, ra, alpha, beta, prev.data(), prev.data() + k * L64, k, add_bc, mul_bc)));   // utils.rs:84-135
+        uint64_t ar[6], mr[6];
+        ZK_TRY(zk_mle_evaluate(add_bc.get(), ch.data(), rounds, ar));
+        ZK_TRY(zk_mle_evaluate(mul_bc.get(), ch.data(), rounds, mr));
+        Fe<F> wb = load_el<F>(wbe), wc = load_el<F>(wce);
+        Fe<F> expect = fe_add<F>(fe_mul<F>(load_el<F>(ar), fe_add<F>(wb, wc)), fe_mul<F>(load_el<F>(mr), fe_mul<F>(wb, wc)));
+        if (!fe_eq<F>(expect, load_el<F>(last))) return ZK_OK;                       // :221-223
+        prev = ch;                                                                   // :225
+        tr.t.append_be<F>(wb);                                                       // :227
+        Fe<F> a = tr.t.random_challenge_as_field_element<F>();
+        tr.t.append_be<F>(wc);                                                       // :230
+        Fe<F> b = tr.t.random_challenge_as_field_element<F>();
+        store_el<F>(alpha, a);
+        store_el<F>(beta, b);
+        store_el<F>(claim, fe_add<F>(fe_mul<F>(a, wb), fe_mul<F>(b, wc)));           // :233
+        goff += gate_counts[L];
+        coff += rounds * 3;
+    }
+    *ok = 1;
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t zk_num_of_layer_variables(size_t layer_index) {
+    if (layer_index == 0) return 3;                       // arithmetic_circuit.rs:167-169
+    return layer_index + 2 * (layer_index + 1);           // :171-177
+}
+size_t zk_wiring_index(size_t layer_index, size_t a, size_t b, size_t c) {
+    size_t wb = padded_bits(b, layer_index + 1), wc = padded_bits(c, layer_index + 1);
+    return (((a << wb) | b) << wc) | c;                   // a-digits ++ b-digits ++ c-digits, :186-195
+}
+size_t zk_gkr_rounds(size_t layer_index) { return 2 * (layer_index + 1); }
+size_t zk_circuit_eval_size(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, size_t ninputs) {
+    size_t tot = ninputs, off = 0;
+    for (size_t l = 0; l < nlayers; l++) { tot += layer_len(gates + off, gate_counts[l]); off += gate_counts[l]; }
+    return tot;
+}
+int zk_circuit_evaluate(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *inputs,
+                        size_t ninputs, size_t *layer_sizes, uint64_t *evals) {
+    if (!gates || !gate_counts || !inputs || !layer_sizes || !evals) return ZK_E_ARG;
+    ZK_DISPATCH_FIELD(field, {
+        CircuitEval ce;
+        ZK_TRY((circuit_evaluate<F>(gates, gate_counts, nlayers, inputs, ninputs, ce)));
+        for (size_t l = 0; l <= nlayers; l++) layer_sizes[l] = ce.lsz[l];
+        memcpy(evals, ce.evals.data(), ce.evals.size() * 8);
+    });
+    return ZK_OK;
+}
+int zk_circuit_add_mul_mle(int field, const zk_gate *layer_gates, size_t ngates, size_t layer_index, zk_table **add_i, zk_table **mul_i) {
+    if ((!layer_gates && ngates) || !add_i || !mul_i) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    TablePtr a, m;
+    ZK_DISPATCH_FIELD(field, ZK_TRY((add_mul_mle<F>(layer_gates, ngates, layer_index, a, m))));
+    *add_i = a.release();
+    *mul_i = m.release();
+    return ZK_OK;
+}
+int zk_gkr_prove(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *inputs, size_t ninputs,
+                 uint64_t *circuit_output, size_t *output_len, uint64_t *claimed_sum, uint64_t *layer_claims, uint64_t *coeffs,
+                 uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals) {
+    if (!gates || !gate_counts || !inputs || !circuit_output || !output_len || !claimed_sum || !layer_claims || !coeffs || !challenges)
+        return ZK_E_ARG;
+    if (nlayers > 1 && (!wb_evals || !wc_evals)) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(field, return gkr_prove<F>(gates, gate_counts, nlayers, inputs, ninputs, circuit_output, output_len, claimed_sum,
+                                                 layer_claims, coeffs, challenges, wb_evals, wc_evals));
+    return ZK_OK;
+}
+int zk_gkr_verify(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *inputs, size_t ninputs,
+                  const uint64_t *circuit_output, size_t output_len, const uint64_t *layer_claims, const uint64_t *coeffs,
+                  const uint64_t *wb_evals, const uint64_t *wc_evals, int *ok) {
+    if (!gates || !gate_counts || !inputs || !circuit_output || !layer_claims || !coeffs || !ok) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(field, return gkr_verify<F>(gates, gate_counts, nlayers, inputs, ninputs, circuit_output, output_len, layer_claims,
+                                                  coeffs, wb_evals, wc_evals, ok));
+    return ZK_OK;
+}
+
+}  // extern "C"
