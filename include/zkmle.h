@@ -60,6 +60,8 @@ int zk_device_synchronize(void);
 typedef struct zk_table zk_table;
 int zk_table_alloc(int field, size_t len, zk_table **out);                 /* uninitialised */
 int zk_table_upload(int field, const uint64_t *host, size_t len, zk_table **out);  /* MultilinearPolynomial::new :12 (asserts pow2) */
+/* plain vector upload without the power-of-two assert (MSM scalars, W layers): any len >= 1 */
+int zk_table_upload_raw(int field, const uint64_t *host, size_t len, zk_table **out);
 int zk_table_download(const zk_table *t, uint64_t *host);
 int zk_table_free(zk_table *t);
 size_t zk_table_len(const zk_table *t);
@@ -180,6 +182,45 @@ int zk_gkr_verify(int field, const zk_gate *gates, const size_t *gate_counts, si
                   const uint64_t *inputs, size_t ninputs, const uint64_t *circuit_output, size_t output_len,
                   const uint64_t *layer_claims, const uint64_t *coeffs, const uint64_t *wb_evals,
                   const uint64_t *wc_evals, int *ok);
+
+/* ---- BLS12-381 G1 bases, MSM and multilinear KZG (multilinear_kzg/src) ---------------------------
+ * Affine point = 12 u64: x[6] | y[6], Fq Montgomery limbs; x = y = 0 encodes infinity.  Group
+ * results are affine-normalised: compare them as (x, y) (a projective triple is not unique). */
+typedef struct zk_g1_bases zk_g1_bases;                 /* HBM-resident affine bases (TrustedSetup.g1_powers_of_tau, trusted_setup.rs:5-8) */
+int zk_g1_bases_upload(const uint64_t *affine, size_t n, zk_g1_bases **out);
+int zk_g1_bases_download(const zk_g1_bases *b, uint64_t *affine);
+int zk_g1_bases_free(zk_g1_bases *b);
+size_t zk_g1_bases_len(const zk_g1_bases *b);
+/* synthetic benchmark bases P_i = [a + i*d] G, generated on the device */
+int zk_g1_bases_synthetic(size_t n, const uint64_t *a_fr, const uint64_t *d_fr, zk_g1_bases **out);
+int zk_g1_generator(uint64_t *out12);
+int zk_g1_is_on_curve(const uint64_t *p12);
+
+typedef struct {
+    int window_bits, windows;
+    uint64_t terms, entries, segments;
+    float ms_digits, ms_sort, ms_buckets, ms_reduce, ms_total;    /* HIP-event times of the phases */
+} zk_msm_stats;
+/* sum_i [s_i] B_i by Pippenger (window_bits = 0: chosen from n).  scalars: Fr table of n terms
+ * (n = bases length, any n >= 1).  This is the dot product of multilinear_kzg.rs:37-42 / :100-107. */
+int zk_msm_g1(const zk_table *scalars, const zk_g1_bases *bases, int window_bits, uint64_t *out12,
+              zk_msm_stats *stats /* may be NULL */);
+
+/* compute_lagrange_basis  trusted_setup.rs:24-49 : eq table of tau, built in HBM (O(2^n)) */
+int zk_kzg_lagrange_basis(const uint64_t *taus, size_t ntaus, zk_table **out);
+/* compute_g1_powers_of_tau :51-60 : [L_i(tau)] G for all i (fixed-base windowed scalar mul) */
+int zk_kzg_setup_g1(const uint64_t *taus, size_t ntaus, zk_g1_bases **out);
+/* commit_to_polynomial  multilinear_kzg.rs:25-45 */
+int zk_kzg_commit(const zk_table *poly, const zk_g1_bases *g1_powers, uint64_t *out12);
+/* open_and_prove :50-126.  The reference runs a full-size naive dot product per round over the
+ * blown-up quotient; the same group elements are obtained here as MSMs of sizes 2^(n-1) .. 1
+ * against pre-summed bases (zk_kzg_opening_key, built once per setup).  n_g2 = the setup's
+ * g2_powers_of_tau length (only compared, :60-64).  proofs: nopen affine points. */
+typedef struct zk_kzg_opening_key zk_kzg_opening_key;
+int zk_kzg_opening_key_new(const zk_g1_bases *g1_powers, zk_kzg_opening_key **out);
+int zk_kzg_opening_key_free(zk_kzg_opening_key *k);
+int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg_opening_key *key,
+                const uint64_t *opening, size_t nopen, size_t n_g2, uint64_t *evaluation, uint64_t *proofs);
 
 #ifdef __cplusplus
 }

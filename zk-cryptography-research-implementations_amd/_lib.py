@@ -60,6 +60,7 @@ def lib():
         "zk_device_synchronize": [],
         "zk_table_alloc": [C.c_int, sz, C.POINTER(vp)],
         "zk_table_upload": [C.c_int, u64p, sz, C.POINTER(vp)],
+        "zk_table_upload_raw": [C.c_int, u64p, sz, C.POINTER(vp)],
         "zk_table_download": [vp, u64p],
         "zk_table_free": [vp],
         "zk_table_len": [vp],

@@ -149,6 +149,10 @@ int zk_table_alloc(int field, size_t len, zk_table **out) {
 int zk_table_upload(int field, const uint64_t *host, size_t len, zk_table **out) {
     if (!host || !out) return ZK_E_ARG;
     if (!is_pow2(len)) return ZK_E_NOT_POW2;   // MultilinearPolynomial::new, evaluation_form.rs:13
+    return zk_table_upload_raw(field, host, len, out);
+}
+int zk_table_upload_raw(int field, const uint64_t *host, size_t len, zk_table **out) {
+    if (!host || !out) return ZK_E_ARG;
     ZK_TRY(zk_table_alloc(field, len, out));
     hipError_t e = hipMemcpy((*out)->dptr, host, len * (size_t)field_limbs64(field) * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) {

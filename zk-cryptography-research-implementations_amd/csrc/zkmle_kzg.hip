@@ -1,0 +1,404 @@
+// zkmle_kzg.hip -- C ABI: G1 bases in HBM, Pippenger MSM, and the multilinear-KZG prover side
+// (trusted-setup G1 powers, commit, open).  Mirrors multilinear_kzg/src/{multilinear_kzg,trusted_setup}.rs;
+// pairing-based `verify` (G2 / GT) is out of scope.
+#include <string.h>
+
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "context.h"
+#include "msm_kernels.cuh"
+
+using namespace zk;
+
+struct zk_g1_bases {
+    size_t n;
+    void *dptr;   // n affine points, 96 B each
+};
+struct zk_kzg_opening_key {
+    // level[t] (t = 1..nvars): 2^(nvars - t) pre-summed affine bases B^(t)_k = sum_{h < 2^t} B_{h 2^(nvars-t) + k}
+    std::vector<zk_g1_bases *> level;
+    size_t nvars;
+};
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { ZK_HIP(hipMalloc(&p, bytes ? bytes : 16)); return ZK_OK; }
+};
+struct Events {
+    hipEvent_t e[8];
+    int n = 0;
+    ~Events() { for (int i = 0; i < n; i++) (void)hipEventDestroy(e[i]); }
+    int mark() { ZK_HIP(hipEventCreate(&e[n])); ZK_HIP(hipEventRecord(e[n], nullptr)); n++; return ZK_OK; }
+    float ms(int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, e[a], e[b]); return v; }
+};
+
+template <class F> Fe<F> load_el(const uint64_t *src) { Fe<F> e; memcpy(e.l, src, 4 * F::N); return e; }
+
+void affine_to_u64(const G1Affine &p, uint64_t *out12) {
+    memcpy(out12, p.x.l, 48);
+    memcpy(out12 + 6, p.y.l, 48);
+}
+G1Affine affine_from_u64(const uint64_t *in12) {
+    G1Affine p;
+    memcpy(p.x.l, in12, 48);
+    memcpy(p.y.l, in12 + 6, 48);
+    return p;
+}
+
+int pick_window(size_t n) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = lg - 6;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return c;
+}
+
+// sum_i [s_i] B_i ; result as XYZZ on the host
+int msm_device(const void *d_scalars, const void *d_bases, size_t n, int c, G1Xyzz *result, zk_msm_stats *stats) {
+    if (c == 0) c = pick_window(n);
+    if (c < 2 || c > 16) return ZK_E_ARG;
+    if (n >= ((size_t)1 << 31)) return ZK_E_ARG;            // index + sign are packed in 32 bits
+    const unsigned nwin = (256 + c - 1) / c, nb = 1u << (c - 1);
+    const size_t nbuckets = (size_t)nwin * nb;
+    size_t chunk_len = (n + 127) / 128;
+    if (chunk_len < 4096) chunk_len = 4096;
+    const unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
+    unsigned seg_len = (unsigned)(4 * (n / nb + 1));
+    if (seg_len < 32) seg_len = 32;
+    Events ev;
+    ZK_TRY(ev.mark());
+    DevBuf digits, hist, totals, starts, seg_starts, sorted, partials, A, R;
+    ZK_TRY(digits.alloc((size_t)nwin * n * 2));
+    ZK_TRY(hist.alloc((size_t)nwin * nchunks * nb * 4));
+    ZK_TRY(totals.alloc(nbuckets * 4));
+    ZK_TRY(starts.alloc((nbuckets + 1) * 8));
+    ZK_TRY(seg_starts.alloc((nbuckets + 1) * 4));
+    msm_digits_kernel<<<grid_for(n), kBlock>>>(d_scalars, n, (unsigned)c, nwin, (uint16_t *)digits.p);
+    ZK_HIP(hipGetLastError());
+    ZK_TRY(ev.mark());
+    // counting sort, bucket counters staged in LDS
+    size_t lds_bytes = (size_t)nb * 4;
+    ZK_HIP(hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    ZK_HIP(hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    msm_hist_kernel<<<nwin * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len, (uint32_t *)hist.p);
+    msm_chunk_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock>>>((uint32_t *)hist.p, nwin, nchunks, nb, (uint32_t *)totals.p);
+    msm_bucket_scan_kernel<<<1, kSortBlock>>>((const uint32_t *)totals.p, nbuckets, seg_len, (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
+    ZK_HIP(hipGetLastError());
+    uint64_t entries = 0;
+    uint32_t nseg = 0;
+    ZK_HIP(hipMemcpy(&entries, (uint64_t *)starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
+    ZK_HIP(hipMemcpy(&nseg, (uint32_t *)seg_starts.p + nbuckets, 4, hipMemcpyDeviceToHost));
+    ZK_TRY(sorted.alloc((entries ? entries : 1) * 4));
+    msm_scatter_kernel<<<nwin * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len,
+                                                                   (const uint32_t *)hist.p, (const uint64_t *)starts.p, (uint32_t *)sorted.p);
+    ZK_HIP(hipGetLastError());
+    ZK_TRY(ev.mark());
+    // bucket sums
+    ZK_TRY(partials.alloc(((size_t)nseg ? nseg : 1) * sizeof(G1Xyzz)));
+    size_t red_bytes = ((size_t)nwin << c) * sizeof(G1Xyzz);
+    ZK_TRY(A.alloc(red_bytes));
+    ZK_TRY(R.alloc(red_bytes));
+    ZK_HIP(hipMemsetAsync(A.p, 0, red_bytes, nullptr));     // all-zero XYZZ = infinity (ZZ = 0)
+    ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, nullptr));
+    if (nseg) {
+        msm_bucket_sum_kernel<<<(nseg + 255) / 256, 256>>>(d_bases, (const uint32_t *)sorted.p, (const uint64_t *)starts.p,
+                                                           (const uint32_t *)seg_starts.p, nbuckets, seg_len, nseg, partials.p);
+        ZK_HIP(hipGetLastError());
+    }
+    msm_bucket_combine_kernel<<<(unsigned)((nbuckets + 255) / 256), 256>>>(partials.p, (const uint32_t *)seg_starts.p, nwin, (unsigned)c, A.p);
+    ZK_HIP(hipGetLastError());
+    ZK_TRY(ev.mark());
+    // bucket reduction: c halving levels, in place
+    for (size_t half = (size_t)1 << (c - 1); half >= 1; half >>= 1) {
+        size_t work = (size_t)nwin * half;
+        msm_reduce_level_kernel<<<(unsigned)((work + 255) / 256), 256>>>(A.p, R.p, nwin, (unsigned)c, half);
+        ZK_HIP(hipGetLastError());
+        if (half == 1) break;
+    }
+    std::vector<G1Xyzz> sums(nwin);
+    for (unsigned w = 0; w < nwin; w++)
+        ZK_HIP(hipMemcpyAsync(&sums[w], (char *)R.p + ((size_t)w << c) * sizeof(G1Xyzz), sizeof(G1Xyzz), hipMemcpyDeviceToHost, nullptr));
+    ZK_TRY(ev.mark());
+    ZK_HIP(hipDeviceSynchronize());
+    // window combination (host, W points): acc = 2^c * acc + S_w from the top window down
+    G1Xyzz acc = g1_xyzz_inf();
+    for (int w = (int)nwin - 1; w >= 0; w--) {
+        for (int k = 0; k < c; k++) acc = g1_dbl(acc);
+        acc = g1_add(acc, sums[w]);
+    }
+    *result = acc;
+    if (stats) {
+        stats->window_bits = c;
+        stats->windows = (int)nwin;
+        stats->terms = n;
+        stats->entries = entries;
+        stats->segments = nseg;
+        stats->ms_digits = ev.ms(0, 1);
+        stats->ms_sort = ev.ms(1, 2);
+        stats->ms_buckets = ev.ms(2, 3);
+        stats->ms_reduce = ev.ms(3, 4);
+        stats->ms_total = ev.ms(0, 4);
+    }
+    return ZK_OK;
+}
+
+int bases_alloc(size_t n, zk_g1_bases **out) {
+    void *d = nullptr;
+    ZK_HIP(hipMalloc(&d, n * sizeof(G1Affine)));
+    *out = new zk_g1_bases{n, d};
+    return ZK_OK;
+}
+
+// XYZZ (device) -> affine bases (device)
+int normalize_to_bases(const void *d_xyzz, size_t n, zk_g1_bases **out) {
+    ZK_TRY(bases_alloc(n, out));
+    size_t threads = (n + kNormPer - 1) / kNormPer;
+    batch_to_affine_kernel<<<(unsigned)((threads + 255) / 256), 256>>>(d_xyzz, n, (*out)->dptr);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipDeviceSynchronize());
+    return ZK_OK;
+}
+
+// byte-window table of the generator: table[j * 256 + v] = [v * 256^j] G, built once per device on the host
+std::mutex g_tab_mu;
+std::vector<void *> g_gen_table;
+int generator_table(const void **out) {
+    int dev = 0;
+    ZK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    if ((int)g_gen_table.size() <= dev) g_gen_table.resize(dev + 1, nullptr);
+    if (!g_gen_table[dev]) {
+        std::vector<G1Xyzz> tab(32 * 256);
+        G1Xyzz base = g1_from_affine(g1_generator());
+        for (int j = 0; j < 32; j++) {
+            tab[j * 256] = g1_xyzz_inf();
+            for (int v = 1; v < 256; v++) tab[j * 256 + v] = g1_add(tab[j * 256 + v - 1], base);
+            for (int k = 0; k < 8; k++) base = g1_dbl(base);
+        }
+        // batch normalisation on the host: one inversion for the whole table
+        std::vector<FqE> prefix(tab.size());
+        FqE run = fe_one<Fq>();
+        for (size_t i = 0; i < tab.size(); i++) {
+            prefix[i] = run;
+            if (!g1_is_inf(tab[i])) run = fe_mul<Fq>(run, fe_mul<Fq>(tab[i].zz, tab[i].zzz));
+        }
+        FqE inv = fe_inv<Fq>(run);
+        std::vector<G1Affine> aff(tab.size());
+        for (size_t i = tab.size(); i-- > 0;) {
+            if (g1_is_inf(tab[i])) { aff[i].x = fe_zero<Fq>(); aff[i].y = fe_zero<Fq>(); continue; }
+            FqE t = fe_mul<Fq>(inv, prefix[i]);
+            inv = fe_mul<Fq>(inv, fe_mul<Fq>(tab[i].zz, tab[i].zzz));
+            aff[i].x = fe_mul<Fq>(tab[i].x, fe_mul<Fq>(t, tab[i].zzz));
+            aff[i].y = fe_mul<Fq>(tab[i].y, fe_mul<Fq>(t, tab[i].zz));
+        }
+        void *d = nullptr;
+        ZK_HIP(hipMalloc(&d, aff.size() * sizeof(G1Affine)));
+        ZK_HIP(hipMemcpy(d, aff.data(), aff.size() * sizeof(G1Affine), hipMemcpyHostToDevice));
+        g_gen_table[dev] = d;
+    }
+    *out = g_gen_table[dev];
+    return ZK_OK;
+}
+
+int lagrange_basis_device(const uint64_t *taus, size_t ntaus, zk_table **out) {
+    if (!taus || ntaus == 0 || ntaus > 40) return ZK_E_ARG;       // "requires at least one variable" trusted_setup.rs:26
+    size_t n = (size_t)1 << ntaus;
+    zk_table *a = nullptr, *b = nullptr;
+    ZK_TRY(zk_table_alloc(ZK_FR381, n, &a));
+    int rc = zk_table_alloc(ZK_FR381, n, &b);
+    if (rc != ZK_OK) { zk_table_free(a); return rc; }
+    Fe<Fr381> one = fe_one<Fr381>();
+    hipError_t e = hipMemcpy(a->dptr, one.l, 32, hipMemcpyHostToDevice);
+    zk_table *cur = a, *nxt = b;
+    size_t len = 1;
+    for (size_t i = 0; i < ntaus && e == hipSuccess; i++) {       // variable 0 (MSB) first: index bit (n-1-i), :36
+        eq_expand_kernel<<<grid_for(len), kBlock>>>(cur->dptr, nxt->dptr, len, load_el<Fr381>(taus + 4 * i));
+        e = hipGetLastError();
+        zk_table *t = cur; cur = nxt; nxt = t;
+        len *= 2;
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    zk_table_free(nxt);
+    if (e != hipSuccess) { zk_table_free(cur); ZK_HIP(e); }
+    cur->len = n;
+    *out = cur;
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zk_g1_bases_upload(const uint64_t *affine, size_t n, zk_g1_bases **out) {
+    if (!affine || !out || n == 0) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_TRY(bases_alloc(n, out));
+    hipError_t e = hipMemcpy((*out)->dptr, affine, n * sizeof(G1Affine), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { zk_g1_bases_free(*out); *out = nullptr; ZK_HIP(e); }
+    return ZK_OK;
+}
+int zk_g1_bases_download(const zk_g1_bases *b, uint64_t *affine) {
+    if (!b || !affine) return ZK_E_ARG;
+    ZK_HIP(hipMemcpy(affine, b->dptr, b->n * sizeof(G1Affine), hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+int zk_g1_bases_free(zk_g1_bases *b) {
+    if (!b) return ZK_OK;
+    if (b->dptr) ZK_HIP(hipFree(b->dptr));
+    delete b;
+    return ZK_OK;
+}
+size_t zk_g1_bases_len(const zk_g1_bases *b) { return b ? b->n : 0; }
+
+int zk_g1_generator(uint64_t *out12) {
+    if (!out12) return ZK_E_ARG;
+    affine_to_u64(g1_generator(), out12);
+    return ZK_OK;
+}
+int zk_g1_is_on_curve(const uint64_t *p12) {
+    if (!p12) return ZK_E_ARG;
+    return g1_on_curve(affine_from_u64(p12)) ? 1 : 0;
+}
+
+int zk_g1_bases_synthetic(size_t n, const uint64_t *a_fr, const uint64_t *d_fr, zk_g1_bases **out) {
+    if (!a_fr || !d_fr || !out || n == 0) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    Fe<Fr381> a = fe_to_canonical<Fr381>(load_el<Fr381>(a_fr)), d = fe_to_canonical<Fr381>(load_el<Fr381>(d_fr));
+    G1Affine g = g1_generator();
+    G1Affine dstep = g1_to_affine(g1_mul_canonical(g, d.l, 8));
+    DevBuf xyzz;
+    ZK_TRY(xyzz.alloc(n * sizeof(G1Xyzz)));
+    const unsigned per = 64;
+    size_t threads = (n + per - 1) / per;
+    synthetic_bases_kernel<<<(unsigned)((threads + 255) / 256), 256>>>(g, dstep, a, d, n, per, xyzz.p);
+    ZK_HIP(hipGetLastError());
+    return normalize_to_bases(xyzz.p, n, out);
+}
+
+int zk_msm_g1(const zk_table *scalars, const zk_g1_bases *bases, int window_bits, uint64_t *out12, zk_msm_stats *stats) {
+    if (!scalars || !bases || !out12) return ZK_E_ARG;
+    if (scalars->field != ZK_FR381) return ZK_E_ARG;
+    if (scalars->len != bases->n) return ZK_E_KZG_LEN;
+    ZK_TRY(require_device());
+    G1Xyzz r;
+    ZK_TRY(msm_device(scalars->dptr, bases->dptr, scalars->len, window_bits, &r, stats));
+    affine_to_u64(g1_to_affine(r), out12);
+    return ZK_OK;
+}
+
+int zk_kzg_lagrange_basis(const uint64_t *taus, size_t ntaus, zk_table **out) {
+    if (!out) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    return lagrange_basis_device(taus, ntaus, out);
+}
+
+int zk_kzg_setup_g1(const uint64_t *taus, size_t ntaus, zk_g1_bases **out) {
+    if (!out) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    zk_table *basis = nullptr;
+    ZK_TRY(lagrange_basis_device(taus, ntaus, &basis));              // trusted_setup.rs:12
+    size_t n = basis->len;
+    const void *table = nullptr;
+    DevBuf xyzz;
+    int rc = generator_table(&table);
+    if (rc == ZK_OK) rc = xyzz.alloc(n * sizeof(G1Xyzz));
+    if (rc == ZK_OK) {
+        fixed_base_mul_kernel<<<(unsigned)((n + 255) / 256), 256>>>(basis->dptr, n, table, xyzz.p);   // :51-60
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
+    }
+    if (rc == ZK_OK) rc = normalize_to_bases(xyzz.p, n, out);
+    zk_table_free(basis);
+    return rc;
+}
+
+int zk_kzg_commit(const zk_table *poly, const zk_g1_bases *g1_powers, uint64_t *out12) {
+    if (!poly || !g1_powers || !out12) return ZK_E_ARG;
+    if (poly->field != ZK_FR381) return ZK_E_ARG;
+    if (poly->len != g1_powers->n) return ZK_E_KZG_LEN;              // multilinear_kzg.rs:29-33
+    return zk_msm_g1(poly, g1_powers, 0, out12, nullptr);
+}
+
+int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
+    if (!g1 || !out) return ZK_E_ARG;
+    if (!is_pow2(g1->n)) return ZK_E_NOT_POW2;
+    ZK_TRY(require_device());
+    std::unique_ptr<zk_kzg_opening_key> key(new zk_kzg_opening_key());
+    key->nvars = ilog2(g1->n);
+    key->level.assign(key->nvars + 1, nullptr);
+    const zk_g1_bases *cur = g1;
+    int rc = ZK_OK;
+    for (size_t t = 1; t <= key->nvars && rc == ZK_OK; t++) {
+        size_t half = cur->n / 2;
+        DevBuf xyzz;
+        rc = xyzz.alloc(half * sizeof(G1Xyzz));
+        if (rc != ZK_OK) break;
+        g1_pair_add_kernel<<<(unsigned)((half + 255) / 256), 256>>>(cur->dptr, half, xyzz.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; break; }
+        rc = normalize_to_bases(xyzz.p, half, &key->level[t]);
+        cur = key->level[t];
+    }
+    if (rc != ZK_OK) { zk_kzg_opening_key_free(key.release()); return rc; }
+    *out = key.release();
+    return ZK_OK;
+}
+int zk_kzg_opening_key_free(zk_kzg_opening_key *k) {
+    if (!k) return ZK_OK;
+    for (zk_g1_bases *b : k->level) zk_g1_bases_free(b);
+    delete k;
+    return ZK_OK;
+}
+
+int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg_opening_key *key, const uint64_t *opening,
+                size_t nopen, size_t n_g2, uint64_t *evaluation, uint64_t *proofs) {
+    if (!poly || !g1_powers || !opening || !evaluation || !proofs) return ZK_E_ARG;
+    if (poly->field != ZK_FR381) return ZK_E_ARG;
+    if (!is_pow2(poly->len)) return ZK_E_NOT_POW2;
+    if (ilog2(poly->len) != nopen) return ZK_E_KZG_LEN;              // :55-59
+    if (nopen != n_g2) return ZK_E_KZG_LEN;                          // :60-64
+    if (poly->len != g1_powers->n) return ZK_E_KZG_LEN;              // the zip of :100-103 needs equal lengths (asserted at commit :29)
+    ZK_TRY(require_device());
+    zk_kzg_opening_key *own = nullptr;
+    if (!key) {
+        ZK_TRY(zk_kzg_opening_key_new(g1_powers, &own));
+        key = own;
+    }
+    int rc = ZK_OK;
+    if (key->nvars != nopen) rc = ZK_E_KZG_LEN;
+    zk_table *sub = nullptr, *nxt = nullptr, *q = nullptr;
+    if (rc == ZK_OK) rc = zk_mle_evaluate(poly, opening, nopen, evaluation);                    // :70
+    if (rc == ZK_OK) rc = zk_table_alloc(ZK_FR381, poly->len, &sub);
+    if (rc == ZK_OK) rc = zk_mle_sub_scalar(poly, evaluation, sub, nullptr);                    // :74-80
+    if (rc == ZK_OK && poly->len >= 2) rc = zk_table_alloc(ZK_FR381, poly->len / 2, &nxt);
+    if (rc == ZK_OK && poly->len >= 2) rc = zk_table_alloc(ZK_FR381, poly->len / 2, &q);
+    for (size_t i = 0; i < nopen && rc == ZK_OK; i++) {                                          // :86
+        size_t half = sub->len / 2;
+        // quotient = hi half - lo half (compute_quotient_polynomial :165-179)
+        elementwise_kernel<Fr381, OP_HI_MINUS_LO><<<grid_for(half), kBlock>>>(sub->dptr, nullptr, q->dptr, half, fe_zero<Fr381>());
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; break; }
+        q->len = half;
+        // proof_i = sum_j [blown_up(q)[j]] B_j  (:96-107)  ==  sum_k [q[k]] B^(i+1)_k
+        G1Xyzz pi;
+        rc = msm_device(q->dptr, key->level[i + 1]->dptr, half, 0, &pi, nullptr);
+        if (rc != ZK_OK) break;
+        affine_to_u64(g1_to_affine(pi), proofs + 12 * i);
+        nxt->len = half;
+        rc = zk_mle_fold(sub, 0, opening + 4 * i, nxt, nullptr);                                 // :113-119
+        zk_table *t = sub; sub = nxt; nxt = t;
+    }
+    zk_table_free(sub);
+    zk_table_free(nxt);
+    zk_table_free(q);
+    zk_kzg_opening_key_free(own);
+    return rc;
+}
+
+}  // extern "C"

@@ -81,6 +81,14 @@ class MultilinearPolynomial:
         return cls(field, from_ints(field, ints))
 
     @classmethod
+    def vector(cls, field, values):
+        """a plain HBM vector of any length >= 1 (no power-of-two assert): MSM scalars"""
+        vals = np.ascontiguousarray(values, np.uint64).reshape(-1, limbs(field))
+        h = C.c_void_p()
+        L.check(L.lib().zk_table_upload_raw(field, L.p64(vals), vals.shape[0], C.byref(h)))
+        return cls(field, _handle=h)
+
+    @classmethod
     def alloc(cls, field, length):
         h = C.c_void_p()
         L.check(L.lib().zk_table_alloc(field, length, C.byref(h)))
