@@ -96,7 +96,7 @@ def test_msm_vs_naive_oracle(zk, n, c):
     # the synthetic generator itself: P_i = [a + i d] G
     g = O.g1_generator()
     ai, di = O.to_ints(O.FR381, np.stack([a, d]))
-    for i in (0, 1, n - 1):
+    for i in sorted({0, min(1, n - 1), n - 1}):
         assert O.g1_affine_ints(pts[i]) == M.g1_mul(M.G1, (ai + i * di) % R)
     st = zk.MultilinearPolynomial.vector(0, scalars)
     got, stats = zk.kzg.msm(st, bases, window_bits=c, with_stats=True)

@@ -123,36 +123,6 @@ ZK_HD G1Xyzz g1_add(const G1Xyzz &a, const G1Xyzz &b) {
     return o;
 }
 
-// Out-of-line copies for the cold kernels (bucket reduction, setup): one compiled body per
-// translation unit instead of one per call site keeps hipcc's compile time and code size down.
-// The hot bucket-accumulation loop uses the inlined g1_madd.
-__device__ __noinline__ G1Xyzz g1_add_ni(const G1Xyzz &a, const G1Xyzz &b) { return g1_add(a, b); }
-__device__ __noinline__ G1Xyzz g1_dbl_ni(const G1Xyzz &a) { return g1_dbl(a); }
-__device__ __noinline__ G1Xyzz g1_madd_ni(const G1Xyzz &a, const G1Affine &q) { return g1_madd(a, q); }
-__device__ __noinline__ FqE fq_mul_ni(const FqE &a, const FqE &b) { return fe_mul<Fq>(a, b); }
-__device__ __noinline__ FqE fq_inv_ni(const FqE &a) {
-    FqE acc = fe_one<Fq>(), base = a;
-    uint32_t borrow = 2;
-    for (int i = 0; i < Fq::N; i++) {
-        uint32_t pi = Fq::p(i);
-        uint32_t e = pi - borrow;
-        borrow = (pi < borrow) ? 1u : 0u;
-        for (int k = 0; k < 32; k++) {
-            if ((e >> k) & 1) acc = fq_mul_ni(acc, base);
-            base = fq_mul_ni(base, base);
-        }
-    }
-    return acc;
-}
-__device__ __noinline__ G1Xyzz g1_mul_canonical_ni(const G1Affine &p, const uint32_t *k, int nlimbs) {
-    G1Xyzz acc = g1_xyzz_inf();
-    for (int i = 32 * nlimbs - 1; i >= 0; i--) {
-        acc = g1_dbl_ni(acc);
-        if ((k[i / 32] >> (i % 32)) & 1) acc = g1_madd_ni(acc, p);
-    }
-    return acc;
-}
-
 // host-side normalisation (one inversion): x = X / ZZ, y = Y / ZZZ
 inline G1Affine g1_to_affine(const G1Xyzz &p) {
     G1Affine r;

@@ -29,6 +29,7 @@ __device__ __forceinline__ unsigned digit_bucket(unsigned enc, unsigned c) {
     return mag ? mag : (1u << (c - 1));
 }
 
+#ifdef ZK_MSM_LIGHT_KERNELS   // defined by the one translation unit that launches them (zkmle_kzg.hip)
 // scalars: n Fr elements (Montgomery).  digits[w * n + i]
 __global__ void msm_digits_kernel(const void *__restrict__ scalars, size_t n, unsigned c, unsigned nwin,
                                   uint16_t *__restrict__ digits) {
@@ -150,67 +151,6 @@ __global__ void msm_scatter_kernel(const uint16_t *__restrict__ digits, size_t n
     }
 }
 
-// step 3: one lane per segment of at most seg_len entries of one bucket
-__global__ void __launch_bounds__(256) msm_bucket_sum_kernel(const void *__restrict__ bases, const uint32_t *__restrict__ sorted,
-                                                             const uint64_t *__restrict__ starts,
-                                                             const uint32_t *__restrict__ seg_starts, size_t nbuckets,
-                                                             unsigned seg_len, uint32_t nseg, void *__restrict__ partials) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nseg) return;
-    // bucket of segment t: last index with seg_starts[idx] <= t (binary search; empty buckets own no segment)
-    size_t lo = 0, hi = nbuckets;
-    while (hi - lo > 1) {
-        size_t mid = (lo + hi) >> 1;
-        if (seg_starts[mid] <= t) lo = mid; else hi = mid;
-    }
-    size_t b = lo;
-    uint64_t first = starts[b] + (uint64_t)(t - seg_starts[b]) * seg_len;
-    uint64_t end = starts[b + 1];
-    if (first + seg_len < end) end = first + seg_len;
-    G1Xyzz acc = g1_xyzz_inf();
-    for (uint64_t e = first; e < end; e++) {
-        uint32_t v = sorted[e];
-        G1Affine p = g1_load_affine(bases, v & 0x7fffffffu);
-        if (v >> 31) p.y = fe_neg<Fq>(p.y);
-        acc = g1_madd(acc, p);
-    }
-    g1_store_xyzz(partials, t, acc);
-}
-
-// bucket (w, b) = sum of its segments' partials, written to slot b + 1 of window w in the
-// 2^c-slot reduction array A (slot index = digit magnitude)
-__global__ void __launch_bounds__(256) msm_bucket_combine_kernel(const void *__restrict__ partials, const uint32_t *__restrict__ seg_starts,
-                                          unsigned nwin, unsigned c, void *__restrict__ A) {
-    unsigned nb = 1u << (c - 1);
-    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (size_t)nwin * nb) return;
-    unsigned w = id / nb, b = id % nb;
-    uint32_t s0 = seg_starts[id], s1 = seg_starts[id + 1];
-    G1Xyzz acc = g1_xyzz_inf();
-    for (uint32_t s = s0; s < s1; s++) acc = g1_add_ni(acc, g1_load_xyzz(partials, s));
-    g1_store_xyzz(A, ((size_t)w << c) + b + 1, acc);
-}
-
-// step 4: one halving level, in place.  half = current length / 2
-__global__ void __launch_bounds__(256) msm_reduce_level_kernel(void *__restrict__ A, void *__restrict__ R, unsigned nwin, unsigned c, size_t half) {
-    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (size_t)nwin * half) return;
-    size_t w = id / half, b = id % half;
-    size_t base = w << c;
-    G1Xyzz alo = g1_load_xyzz(A, base + b), ahi = g1_load_xyzz(A, base + b + half);
-    G1Xyzz rlo = g1_load_xyzz(R, base + b), rhi = g1_load_xyzz(R, base + b + half);
-    g1_store_xyzz(A, base + b, g1_add_ni(alo, ahi));
-    g1_store_xyzz(R, base + b, g1_add_ni(ahi, g1_dbl_ni(g1_add_ni(rlo, rhi))));
-}
-
-// out[k] = in[k] + in[k + half]  (affine + affine -> XYZZ): the pre-summed opening bases
-// B^(t+1)_k = B^(t)_k + B^(t)_{k + half}  
-__global__ void __launch_bounds__(256) g1_pair_add_kernel(const void *__restrict__ in_affine, size_t half, void *__restrict__ out_xyzz) {
-    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= half) return;
-    g1_store_xyzz(out_xyzz, k, g1_madd_ni(g1_from_affine(g1_load_affine(in_affine, k)), g1_load_affine(in_affine, k + half)));
-}
-
 // ---- setup-side kernels ----------------------------------------------------------------------------
 // eq / Lagrange table  L_idx(tau) = prod_i (bit_i(idx) ? tau_i : 1 - tau_i), variable 0 = MSB
 // (compute_lagrange_basis trusted_setup.rs:24-49), built level by level: out has 2 * len entries,
@@ -225,92 +165,19 @@ __global__ void eq_expand_kernel(const void *__restrict__ in, void *__restrict__
     }
 }
 
-// fixed-base scalar multiplication  out[i] = [s_i] G  with a byte-window table of G
-// (table[j * 256 + v] = [v * 256^j] G, affine, 32 x 256 entries): 32 mixed adds per point
-// (compute_g1_powers_of_tau trusted_setup.rs:51-60 does one 255-bit double-and-add per point).
-__global__ void __launch_bounds__(256) fixed_base_mul_kernel(const void *__restrict__ scalars, size_t n, const void *__restrict__ table,
-                                                             void *__restrict__ out_xyzz) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fe<Fr381> k = fe_to_canonical<Fr381>(fe_load<Fr381>(scalars, i));
-    G1Xyzz acc = g1_xyzz_inf();
-    for (int j = 0; j < 32; j++) {
-        unsigned v = (k.l[j >> 2] >> (8 * (j & 3))) & 0xffu;
-        if (v) acc = g1_madd_ni(acc, g1_load_affine(table, (size_t)j * 256 + v));
-    }
-    g1_store_xyzz(out_xyzz, i, acc);
-}
 
-// batch normalisation XYZZ -> affine: each lane owns `per` consecutive points and shares one
-// field inversion among them (Montgomery's trick); zz = 0 stays the infinity encoding (0, 0).
+#endif  // ZK_MSM_LIGHT_KERNELS
+
+// ---- heavy kernels live in their own translation units (compiled in parallel); launchers: ----------
 constexpr int kNormPer = 16;
-__global__ void __launch_bounds__(256) batch_to_affine_kernel(const void *__restrict__ xyzz, size_t n, void *__restrict__ affine) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t lo = t * kNormPer;
-    if (lo >= n) return;
-    size_t cnt = n - lo < (size_t)kNormPer ? n - lo : kNormPer;
-    FqE prefix[kNormPer];
-    FqE run = fe_one<Fq>();
-    for (size_t k = 0; k < cnt; k++) {               // den_k = zz * zzz (or 1 for infinity)
-        G1Xyzz p = g1_load_xyzz(xyzz, lo + k);
-        prefix[k] = run;
-        if (!g1_is_inf(p)) run = fq_mul_ni(run, fq_mul_ni(p.zz, p.zzz));
-    }
-    FqE inv = fq_inv_ni(run);
-    for (size_t k = cnt; k-- > 0;) {
-        G1Xyzz p = g1_load_xyzz(xyzz, lo + k);
-        G1Affine a;
-        if (g1_is_inf(p)) {
-            a.x = fe_zero<Fq>(); a.y = fe_zero<Fq>();
-        } else {
-            FqE t_k = fq_mul_ni(inv, prefix[k]);    // 1 / (zz * zzz)
-            inv = fq_mul_ni(inv, fq_mul_ni(p.zz, p.zzz));
-            a.x = fq_mul_ni(p.x, fq_mul_ni(t_k, p.zzz));
-            a.y = fq_mul_ni(p.y, fq_mul_ni(t_k, p.zz));
-        }
-        g1_store_affine(affine, lo + k, a);
-    }
-}
-
-// synthetic bases P_i = [a + i d] G: lane t starts at [a + t K d] G and steps by [d] G
-__global__ void __launch_bounds__(256) synthetic_bases_kernel(G1Affine g, G1Affine dstep, Fe<Fr381> a_canon, Fe<Fr381> d_canon, size_t n,
-                                                              unsigned per, void *__restrict__ out_xyzz) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t lo = t * per;
-    if (lo >= n) return;
-    // scalar a + lo * d  (mod r not needed for correctness of the group element: plain integer, up to 320 bits)
-    uint32_t k[10];
-    uint64_t carry = 0;
-    uint64_t lo64 = lo;
-    uint32_t m0 = (uint32_t)lo64, m1 = (uint32_t)(lo64 >> 32);
-    // k = a + d * lo   (schoolbook, d: 8 limbs, lo: 2 limbs)
-    uint32_t prod[10];
-    for (int i = 0; i < 10; i++) prod[i] = 0;
-    for (int i = 0; i < 8; i++) {
-        uint64_t c0 = (uint64_t)d_canon.l[i] * m0 + prod[i] + carry;
-        prod[i] = (uint32_t)c0;
-        carry = c0 >> 32;
-    }
-    prod[8] = (uint32_t)carry;
-    carry = 0;
-    for (int i = 0; i < 8; i++) {
-        uint64_t c1 = (uint64_t)d_canon.l[i] * m1 + prod[i + 1] + carry;
-        prod[i + 1] = (uint32_t)c1;
-        carry = c1 >> 32;
-    }
-    prod[9] = (uint32_t)carry;
-    carry = 0;
-    for (int i = 0; i < 10; i++) {
-        uint64_t s = (uint64_t)prod[i] + (i < 8 ? a_canon.l[i] : 0) + carry;
-        k[i] = (uint32_t)s;
-        carry = s >> 32;
-    }
-    G1Xyzz acc = g1_mul_canonical_ni(g, k, 10);
-    size_t cnt = n - lo < (size_t)per ? n - lo : per;
-    for (size_t j = 0; j < cnt; j++) {
-        g1_store_xyzz(out_xyzz, lo + j, acc);
-        acc = g1_madd_ni(acc, dstep);
-    }
-}
+int launch_msm_bucket_sum(const void *bases, const uint32_t *sorted, const uint64_t *starts, const uint32_t *seg_starts,
+                          size_t nbuckets, unsigned seg_len, uint32_t nseg, void *partials, hipStream_t s);
+int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, hipStream_t s);
+int launch_msm_reduce_level(void *A, void *R, unsigned nwin, unsigned c, size_t half, hipStream_t s);
+int launch_g1_pair_add(const void *in_affine, size_t half, void *out_xyzz, hipStream_t s);
+int launch_fixed_base_mul(const void *scalars, size_t n, const void *table, void *out_xyzz, hipStream_t s);
+int launch_batch_to_affine(const void *xyzz, size_t n, void *affine, hipStream_t s);
+int launch_synthetic_bases(const G1Affine &g, const G1Affine &dstep, const Fe<Fr381> &a_canon, const Fe<Fr381> &d_canon, size_t n,
+                           unsigned per, void *out_xyzz, hipStream_t s);
 
 }  // namespace zk

@@ -1,0 +1,47 @@
+// msm_reduce.hip -- Pippenger bucket combination and the log-depth weighted bucket reduction (own TU).
+#include "context.h"
+#include "msm_kernels.cuh"
+
+namespace zk {
+
+// bucket (w, b) = sum of its segments' partials, written to slot b + 1 of window w in the
+// 2^c-slot reduction array A (slot index = digit magnitude)
+__global__ void __launch_bounds__(256) msm_bucket_combine_kernel(const void *__restrict__ partials, const uint32_t *__restrict__ seg_starts,
+                                          unsigned nwin, unsigned c, void *__restrict__ A) {
+    unsigned nb = 1u << (c - 1);
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)nwin * nb) return;
+    unsigned w = id / nb, b = id % nb;
+    uint32_t s0 = seg_starts[id], s1 = seg_starts[id + 1];
+    G1Xyzz acc = g1_xyzz_inf();
+    for (uint32_t s = s0; s < s1; s++) acc = g1_add(acc, g1_load_xyzz(partials, s));
+    g1_store_xyzz(A, ((size_t)w << c) + b + 1, acc);
+}
+
+// step 4: one halving level, in place.  half = current length / 2
+__global__ void __launch_bounds__(256) msm_reduce_level_kernel(void *__restrict__ A, void *__restrict__ R, unsigned nwin, unsigned c, size_t half) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)nwin * half) return;
+    size_t w = id / half, b = id % half;
+    size_t base = w << c;
+    G1Xyzz alo = g1_load_xyzz(A, base + b), ahi = g1_load_xyzz(A, base + b + half);
+    G1Xyzz rlo = g1_load_xyzz(R, base + b), rhi = g1_load_xyzz(R, base + b + half);
+    g1_store_xyzz(A, base + b, g1_add(alo, ahi));
+    g1_store_xyzz(R, base + b, g1_add(ahi, g1_dbl(g1_add(rlo, rhi))));
+}
+
+
+int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, hipStream_t s) {
+    size_t nbuckets = (size_t)nwin << (c - 1);
+    msm_bucket_combine_kernel<<<(unsigned)((nbuckets + 255) / 256), 256, 0, s>>>(partials, seg_starts, nwin, c, A);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int launch_msm_reduce_level(void *A, void *R, unsigned nwin, unsigned c, size_t half, hipStream_t s) {
+    size_t work = (size_t)nwin * half;
+    msm_reduce_level_kernel<<<(unsigned)((work + 255) / 256), 256, 0, s>>>(A, R, nwin, c, half);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+}  // namespace zk

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "context.h"
+#define ZK_MSM_LIGHT_KERNELS
 #include "msm_kernels.cuh"
 
 using namespace zk;
@@ -107,18 +108,14 @@ int msm_device(const void *d_scalars, const void *d_bases, size_t n, int c, G1Xy
     ZK_HIP(hipMemsetAsync(A.p, 0, red_bytes, nullptr));     // all-zero XYZZ = infinity (ZZ = 0)
     ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, nullptr));
     if (nseg) {
-        msm_bucket_sum_kernel<<<(nseg + 255) / 256, 256>>>(d_bases, (const uint32_t *)sorted.p, (const uint64_t *)starts.p,
-                                                           (const uint32_t *)seg_starts.p, nbuckets, seg_len, nseg, partials.p);
-        ZK_HIP(hipGetLastError());
+        ZK_TRY(launch_msm_bucket_sum(d_bases, (const uint32_t *)sorted.p, (const uint64_t *)starts.p, (const uint32_t *)seg_starts.p,
+                                     nbuckets, seg_len, nseg, partials.p, nullptr));
     }
-    msm_bucket_combine_kernel<<<(unsigned)((nbuckets + 255) / 256), 256>>>(partials.p, (const uint32_t *)seg_starts.p, nwin, (unsigned)c, A.p);
-    ZK_HIP(hipGetLastError());
+    ZK_TRY(launch_msm_bucket_combine(partials.p, (const uint32_t *)seg_starts.p, nwin, (unsigned)c, A.p, nullptr));
     ZK_TRY(ev.mark());
     // bucket reduction: c halving levels, in place
     for (size_t half = (size_t)1 << (c - 1); half >= 1; half >>= 1) {
-        size_t work = (size_t)nwin * half;
-        msm_reduce_level_kernel<<<(unsigned)((work + 255) / 256), 256>>>(A.p, R.p, nwin, (unsigned)c, half);
-        ZK_HIP(hipGetLastError());
+        ZK_TRY(launch_msm_reduce_level(A.p, R.p, nwin, (unsigned)c, half, nullptr));
         if (half == 1) break;
     }
     std::vector<G1Xyzz> sums(nwin);
@@ -158,9 +155,7 @@ int bases_alloc(size_t n, zk_g1_bases **out) {
 // XYZZ (device) -> affine bases (device)
 int normalize_to_bases(const void *d_xyzz, size_t n, zk_g1_bases **out) {
     ZK_TRY(bases_alloc(n, out));
-    size_t threads = (n + kNormPer - 1) / kNormPer;
-    batch_to_affine_kernel<<<(unsigned)((threads + 255) / 256), 256>>>(d_xyzz, n, (*out)->dptr);
-    ZK_HIP(hipGetLastError());
+    ZK_TRY(launch_batch_to_affine(d_xyzz, n, (*out)->dptr, nullptr));
     ZK_HIP(hipDeviceSynchronize());
     return ZK_OK;
 }
@@ -274,10 +269,7 @@ int zk_g1_bases_synthetic(size_t n, const uint64_t *a_fr, const uint64_t *d_fr, 
     G1Affine dstep = g1_to_affine(g1_mul_canonical(g, d.l, 8));
     DevBuf xyzz;
     ZK_TRY(xyzz.alloc(n * sizeof(G1Xyzz)));
-    const unsigned per = 64;
-    size_t threads = (n + per - 1) / per;
-    synthetic_bases_kernel<<<(unsigned)((threads + 255) / 256), 256>>>(g, dstep, a, d, n, per, xyzz.p);
-    ZK_HIP(hipGetLastError());
+    ZK_TRY(launch_synthetic_bases(g, dstep, a, d, n, 64, xyzz.p, nullptr));
     return normalize_to_bases(xyzz.p, n, out);
 }
 
@@ -309,9 +301,7 @@ int zk_kzg_setup_g1(const uint64_t *taus, size_t ntaus, zk_g1_bases **out) {
     int rc = generator_table(&table);
     if (rc == ZK_OK) rc = xyzz.alloc(n * sizeof(G1Xyzz));
     if (rc == ZK_OK) {
-        fixed_base_mul_kernel<<<(unsigned)((n + 255) / 256), 256>>>(basis->dptr, n, table, xyzz.p);   // :51-60
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
+        rc = launch_fixed_base_mul(basis->dptr, n, table, xyzz.p, nullptr);   // :51-60
     }
     if (rc == ZK_OK) rc = normalize_to_bases(xyzz.p, n, out);
     zk_table_free(basis);
@@ -339,9 +329,8 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
         DevBuf xyzz;
         rc = xyzz.alloc(half * sizeof(G1Xyzz));
         if (rc != ZK_OK) break;
-        g1_pair_add_kernel<<<(unsigned)((half + 255) / 256), 256>>>(cur->dptr, half, xyzz.p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; break; }
+        rc = launch_g1_pair_add(cur->dptr, half, xyzz.p, nullptr);
+        if (rc != ZK_OK) break;
         rc = normalize_to_bases(xyzz.p, half, &key->level[t]);
         cur = key->level[t];
     }
