@@ -95,26 +95,36 @@ __global__ void msm_chunk_scan_kernel(uint32_t *__restrict__ hist, unsigned nwin
 // counts ceil(count / seg_len).  starts[count] / seg_starts[count] hold the grand totals.
 __global__ void msm_bucket_scan_kernel(const uint32_t *__restrict__ totals, size_t count, unsigned seg_len,
                                        uint64_t *__restrict__ starts, uint32_t *__restrict__ seg_starts) {
+    // seg_starts[count + 1] receives the largest per-bucket segment count
     __shared__ uint64_t sh_e[kSortBlock];
     __shared__ uint32_t sh_s[kSortBlock];
+    __shared__ uint32_t sh_m[kSortBlock];
     size_t per = (count + blockDim.x - 1) / blockDim.x;
     size_t lo = (size_t)threadIdx.x * per, hi = lo + per < count ? lo + per : count;
     uint64_t se = 0;
-    uint32_t ss = 0;
-    for (size_t i = lo; i < hi; i++) { se += totals[i]; ss += (totals[i] + seg_len - 1) / seg_len; }
+    uint32_t ss = 0, mx = 0;
+    for (size_t i = lo; i < hi; i++) {
+        uint32_t segs = (totals[i] + seg_len - 1) / seg_len;
+        se += totals[i];
+        ss += segs;
+        mx = segs > mx ? segs : mx;
+    }
     sh_e[threadIdx.x] = se;
     sh_s[threadIdx.x] = ss;
+    sh_m[threadIdx.x] = mx;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t re = 0;
-        uint32_t rs = 0;
+        uint32_t rs = 0, rm = 0;
         for (unsigned t = 0; t < blockDim.x; t++) {
             uint64_t ve = sh_e[t]; uint32_t vs = sh_s[t];
             sh_e[t] = re; sh_s[t] = rs;
             re += ve; rs += vs;
+            rm = sh_m[t] > rm ? sh_m[t] : rm;
         }
         starts[count] = re;
         seg_starts[count] = rs;
+        seg_starts[count + 1] = rm;
     }
     __syncthreads();
     se = sh_e[threadIdx.x];
@@ -124,6 +134,42 @@ __global__ void msm_bucket_scan_kernel(const uint32_t *__restrict__ totals, size
         seg_starts[i] = ss;
         se += totals[i];
         ss += (totals[i] + seg_len - 1) / seg_len;
+    }
+}
+
+// regrouping scan (one block): out_starts = exclusive scan of ceil(segments(b) / group); out_starts[count] = total,
+// out_starts[count + 1] = the largest regrouped count.  Used by the hierarchical combination of heavy buckets.
+__global__ void msm_regroup_scan_kernel(const uint32_t *__restrict__ in_starts, size_t count, unsigned group,
+                                        uint32_t *__restrict__ out_starts) {
+    __shared__ uint32_t sh_s[kSortBlock];
+    __shared__ uint32_t sh_m[kSortBlock];
+    size_t per = (count + blockDim.x - 1) / blockDim.x;
+    size_t lo = (size_t)threadIdx.x * per, hi = lo + per < count ? lo + per : count;
+    uint32_t ss = 0, mx = 0;
+    for (size_t i = lo; i < hi; i++) {
+        uint32_t g = (in_starts[i + 1] - in_starts[i] + group - 1) / group;
+        ss += g;
+        mx = g > mx ? g : mx;
+    }
+    sh_s[threadIdx.x] = ss;
+    sh_m[threadIdx.x] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t rs = 0, rm = 0;
+        for (unsigned t = 0; t < blockDim.x; t++) {
+            uint32_t vs = sh_s[t];
+            sh_s[t] = rs;
+            rs += vs;
+            rm = sh_m[t] > rm ? sh_m[t] : rm;
+        }
+        out_starts[count] = rs;
+        out_starts[count + 1] = rm;
+    }
+    __syncthreads();
+    ss = sh_s[threadIdx.x];
+    for (size_t i = lo; i < hi; i++) {
+        out_starts[i] = ss;
+        ss += (in_starts[i + 1] - in_starts[i] + group - 1) / group;
     }
 }
 
@@ -172,6 +218,8 @@ __global__ void eq_expand_kernel(const void *__restrict__ in, void *__restrict__
 constexpr int kNormPer = 16;
 int launch_msm_bucket_sum(const void *bases, const uint32_t *sorted, const uint64_t *starts, const uint32_t *seg_starts,
                           size_t nbuckets, unsigned seg_len, uint32_t nseg, void *partials, hipStream_t s);
+int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_starts, const uint32_t *out_starts, size_t nbuckets,
+                                unsigned group, uint32_t nout, void *out_partials, hipStream_t s);
 int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, hipStream_t s);
 int launch_msm_reduce_level(void *A, void *R, unsigned nwin, unsigned c, size_t half, hipStream_t s);
 int launch_g1_pair_add(const void *in_affine, size_t half, void *out_xyzz, hipStream_t s);

@@ -4,6 +4,26 @@
 
 namespace zk {
 
+// heavy buckets: sums of up to `group` consecutive partials of one bucket (one lane per output group)
+__global__ void __launch_bounds__(256) msm_partials_regroup_kernel(const void *__restrict__ in_partials, const uint32_t *__restrict__ in_starts,
+                                                                   const uint32_t *__restrict__ out_starts, size_t nbuckets, unsigned group,
+                                                                   uint32_t nout, void *__restrict__ out_partials) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nout) return;
+    size_t lo = 0, hi = nbuckets;
+    while (hi - lo > 1) {
+        size_t mid = (lo + hi) >> 1;
+        if (out_starts[mid] <= t) lo = mid; else hi = mid;
+    }
+    size_t b = lo;
+    uint32_t first = in_starts[b] + (t - out_starts[b]) * group;
+    uint32_t end = in_starts[b + 1];
+    if (first + group < end) end = first + group;
+    G1Xyzz acc = g1_load_xyzz(in_partials, first);
+    for (uint32_t e = first + 1; e < end; e++) acc = g1_add(acc, g1_load_xyzz(in_partials, e));
+    g1_store_xyzz(out_partials, t, acc);
+}
+
 // bucket (w, b) = sum of its segments' partials, written to slot b + 1 of window w in the
 // 2^c-slot reduction array A (slot index = digit magnitude)
 __global__ void __launch_bounds__(256) msm_bucket_combine_kernel(const void *__restrict__ partials, const uint32_t *__restrict__ seg_starts,
@@ -31,6 +51,12 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(void *__restrict_
 }
 
 
+int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_starts, const uint32_t *out_starts, size_t nbuckets,
+                                unsigned group, uint32_t nout, void *out_partials, hipStream_t s) {
+    msm_partials_regroup_kernel<<<(nout + 255) / 256, 256, 0, s>>>(in_partials, in_starts, out_starts, nbuckets, group, nout, out_partials);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
 int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, hipStream_t s) {
     size_t nbuckets = (size_t)nwin << (c - 1);
     msm_bucket_combine_kernel<<<(unsigned)((nbuckets + 255) / 256), 256, 0, s>>>(partials, seg_starts, nwin, c, A);

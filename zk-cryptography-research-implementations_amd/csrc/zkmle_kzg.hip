@@ -51,13 +51,15 @@ G1Affine affine_from_u64(const uint64_t *in12) {
     return p;
 }
 
+// window size: 255-bit scalars split evenly for c = 16 (top window 15 bits = a full signed digit);
+// smaller problems take smaller windows so the bucket reduction does not dominate
 int pick_window(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = lg - 6;
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
-    return c;
+    if (lg >= 18) return 16;
+    if (lg >= 14) return 13;
+    int c = lg - 3;
+    return c < 4 ? 4 : c;
 }
 
 // sum_i [s_i] B_i ; result as XYZZ on the host
@@ -70,8 +72,10 @@ int msm_device(const void *d_scalars, const void *d_bases, size_t n, int c, G1Xy
     size_t chunk_len = (n + 127) / 128;
     if (chunk_len < 4096) chunk_len = 4096;
     const unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
-    unsigned seg_len = (unsigned)(4 * (n / nb + 1));
-    if (seg_len < 32) seg_len = 32;
+    // one lane per bucket SEGMENT: cap the serial chain so that ~2^20 lanes exist whatever the window
+    // size (measured r1: 2^20 terms, c = 14: 149k lanes -> 0.7e9 add/s; 521k lanes at c = 16 -> 2.1e9 add/s)
+    size_t seg_target = ((size_t)n * nwin) >> 20;
+    unsigned seg_len = (unsigned)(seg_target < 16 ? 16 : seg_target);
     Events ev;
     ZK_TRY(ev.mark());
     DevBuf digits, hist, totals, starts, seg_starts, sorted, partials, A, R;
@@ -79,7 +83,7 @@ int msm_device(const void *d_scalars, const void *d_bases, size_t n, int c, G1Xy
     ZK_TRY(hist.alloc((size_t)nwin * nchunks * nb * 4));
     ZK_TRY(totals.alloc(nbuckets * 4));
     ZK_TRY(starts.alloc((nbuckets + 1) * 8));
-    ZK_TRY(seg_starts.alloc((nbuckets + 1) * 4));
+    ZK_TRY(seg_starts.alloc((nbuckets + 2) * 4));
     msm_digits_kernel<<<grid_for(n), kBlock>>>(d_scalars, n, (unsigned)c, nwin, (uint16_t *)digits.p);
     ZK_HIP(hipGetLastError());
     ZK_TRY(ev.mark());
@@ -92,9 +96,10 @@ int msm_device(const void *d_scalars, const void *d_bases, size_t n, int c, G1Xy
     msm_bucket_scan_kernel<<<1, kSortBlock>>>((const uint32_t *)totals.p, nbuckets, seg_len, (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
     ZK_HIP(hipGetLastError());
     uint64_t entries = 0;
-    uint32_t nseg = 0;
+    uint32_t tail[2] = {0, 0};                              // {segments, largest per-bucket segment count}
     ZK_HIP(hipMemcpy(&entries, (uint64_t *)starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
-    ZK_HIP(hipMemcpy(&nseg, (uint32_t *)seg_starts.p + nbuckets, 4, hipMemcpyDeviceToHost));
+    ZK_HIP(hipMemcpy(tail, (uint32_t *)seg_starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
+    uint32_t nseg = tail[0], max_segs = tail[1];
     ZK_TRY(sorted.alloc((entries ? entries : 1) * 4));
     msm_scatter_kernel<<<nwin * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len,
                                                                    (const uint32_t *)hist.p, (const uint64_t *)starts.p, (uint32_t *)sorted.p);
@@ -111,7 +116,27 @@ int msm_device(const void *d_scalars, const void *d_bases, size_t n, int c, G1Xy
         ZK_TRY(launch_msm_bucket_sum(d_bases, (const uint32_t *)sorted.p, (const uint64_t *)starts.p, (const uint32_t *)seg_starts.p,
                                      nbuckets, seg_len, nseg, partials.p, nullptr));
     }
-    ZK_TRY(launch_msm_bucket_combine(partials.p, (const uint32_t *)seg_starts.p, nwin, (unsigned)c, A.p, nullptr));
+    // heavy buckets (skewed scalars, or the short top window): combine partials 16 at a time until every
+    // bucket has at most 16, so no lane ever runs a long serial chain of full additions
+    const unsigned kGroup = 16;
+    DevBuf lvl_partials[2], lvl_starts[2];
+    const void *cur_partials = partials.p;
+    const uint32_t *cur_starts = (const uint32_t *)seg_starts.p;
+    for (int lvl = 0; max_segs > kGroup; lvl++) {
+        DevBuf &np = lvl_partials[lvl & 1], &ns = lvl_starts[lvl & 1];
+        if (ns.p) { ZK_HIP(hipFree(ns.p)); ns.p = nullptr; }
+        if (np.p) { ZK_HIP(hipFree(np.p)); np.p = nullptr; }
+        ZK_TRY(ns.alloc((nbuckets + 2) * 4));
+        msm_regroup_scan_kernel<<<1, kSortBlock>>>(cur_starts, nbuckets, kGroup, (uint32_t *)ns.p);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpy(tail, (uint32_t *)ns.p + nbuckets, 8, hipMemcpyDeviceToHost));
+        ZK_TRY(np.alloc(((size_t)tail[0] ? tail[0] : 1) * sizeof(G1Xyzz)));
+        ZK_TRY(launch_msm_partials_regroup(cur_partials, cur_starts, (const uint32_t *)ns.p, nbuckets, kGroup, tail[0], np.p, nullptr));
+        cur_partials = np.p;
+        cur_starts = (const uint32_t *)ns.p;
+        max_segs = tail[1];
+    }
+    ZK_TRY(launch_msm_bucket_combine(cur_partials, cur_starts, nwin, (unsigned)c, A.p, nullptr));
     ZK_TRY(ev.mark());
     // bucket reduction: c halving levels, in place
     for (size_t half = (size_t)1 << (c - 1); half >= 1; half >>= 1) {
