@@ -109,6 +109,10 @@ int zk_host_evaluate(int field, const uint64_t *poly, size_t len, const uint64_t
 int zk_fe_from_u64(int field, uint64_t v, uint64_t *out);
 int zk_fe_to_bytes_be(int field, const uint64_t *a, uint8_t *out);
 int zk_fe_from_le_bytes_mod_order(int field, const uint8_t *bytes, size_t n, uint64_t *out);
+int zk_fe_add(int field, const uint64_t *a, const uint64_t *b, uint64_t *out);
+int zk_fe_sub(int field, const uint64_t *a, const uint64_t *b, uint64_t *out);
+int zk_fe_mul(int field, const uint64_t *a, const uint64_t *b, uint64_t *out);
+int zk_fe_inv(int field, const uint64_t *a, uint64_t *out);
 int zk_vec_from_canonical(int field, const uint64_t *canon, size_t n, uint64_t *mont);
 int zk_vec_to_canonical(int field, const uint64_t *mont, size_t n, uint64_t *canon);
 
@@ -144,6 +148,11 @@ int zk_sumpoly_evaluate(const zk_table *const *tables, size_t nprod, size_t nfac
 int zk_sumpoly_reduce(const zk_table *const *tables, size_t nprod, size_t nfac, zk_table *out); /* :57 add_polynomials_element_wise */
 /* generate_round_univariate sumcheck_gkr_protocol.rs:113-143 ; out: nfac+1 evaluations at 0..nfac */
 int zk_sumpoly_round_evals(const zk_table *const *tables, size_t nprod, size_t nfac, uint64_t *out);
+/* one fused prover round on caller-managed tables: fold every table of `in` by `value` into `out`
+ * (len/2 each) and return the NEXT round's nfac+1 evaluations of the folded tables (len >= 4).
+ * Building block of the multi-GPU prover, where the host combines per-shard evaluations. */
+int zk_sumpoly_fold_round_evals(const zk_table *const *in, zk_table *const *out, size_t nprod, size_t nfac,
+                                const uint64_t *value, uint64_t *out_evals);
 /* prove  sumcheck_gkr_protocol.rs:24-67.  round_coeffs: nvars*(nfac+1) coefficients, challenges: nvars.
  * The caller's tables are not modified (the reference clones, :33). */
 int zk_sumcheck_gkr_prove(const zk_table *const *tables, size_t nprod, size_t nfac,
@@ -195,6 +204,9 @@ size_t zk_g1_bases_len(const zk_g1_bases *b);
 int zk_g1_bases_synthetic(size_t n, const uint64_t *a_fr, const uint64_t *d_fr, zk_g1_bases **out);
 int zk_g1_generator(uint64_t *out12);
 int zk_g1_is_on_curve(const uint64_t *p12);
+/* host-side group helpers (control path: combining per-GPU partial results, a handful of points) */
+int zk_g1_add(const uint64_t *p12, const uint64_t *q12, uint64_t *out12);
+int zk_g1_mul_fr(const uint64_t *p12, const uint64_t *scalar_fr, uint64_t *out12);
 
 typedef struct {
     int window_bits, windows;
@@ -221,6 +233,17 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1_powers, zk_kzg_opening_key **ou
 int zk_kzg_opening_key_free(zk_kzg_opening_key *k);
 int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg_opening_key *key,
                 const uint64_t *opening, size_t nopen, size_t n_g2, uint64_t *evaluation, uint64_t *proofs);
+
+/* prove_succinct  gkr/src/succinct_gkr_protocol.rs:35-169 (BLS12-381 Fr): the GKR proof of
+ * zk_gkr_prove plus commit(inputs) (:42-44) and the two openings at the last layer's rb / rc
+ * (:154-157).  rb_proofs / rc_proofs: nlayers affine points each. */
+int zk_gkr_prove_succinct(const zk_gate *gates, const size_t *gate_counts, size_t nlayers,
+                          const uint64_t *inputs, size_t ninputs, const zk_g1_bases *g1_powers, size_t n_g2,
+                          uint64_t *circuit_output, size_t *output_len, uint64_t *claimed_sum,
+                          uint64_t *layer_claims, uint64_t *coeffs, uint64_t *challenges,
+                          uint64_t *wb_evals, uint64_t *wc_evals, uint64_t *commitment12,
+                          uint64_t *rb_evaluation, uint64_t *rb_proofs, uint64_t *rc_evaluation,
+                          uint64_t *rc_proofs);
 
 #ifdef __cplusplus
 }

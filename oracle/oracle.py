@@ -523,6 +523,21 @@ def kzg_quotients(values, opening):
     return res
 
 
+def gkr_prove_succinct(layers, inputs, g1_points, n_g2=None):
+    """prove_succinct, gkr/src/succinct_gkr_protocol.rs:35-169: commit(inputs) :42-44, the layer loop of
+    gkr_protocol::prove (rb / rc are taken from EVERY layer's challenges here, :121-126, so after the loop
+    they are the last layer's), then open(inputs, rb) and open(inputs, rc) :154-157."""
+    x = _arr(FR381, inputs)
+    proof = gkr_prove(FR381, layers, x)
+    proof["input_polynomial_commitment"] = kzg_commit(x, g1_points)
+    last = gkr_rounds(len(layers) - 1)
+    ch = proof["challenges"][-last:]
+    mid = last // 2
+    proof["input_rb_proof"] = kzg_open(x, g1_points, ch[:mid], n_g2)
+    proof["input_rc_proof"] = kzg_open(x, g1_points, ch[mid:], n_g2)
+    return proof
+
+
 # ---- cpu baseline -----------------------------------------------------------------------------
 def bench_fold(field, table, r, reps):
     t = _arr(field, table)

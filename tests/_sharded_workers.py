@@ -1,0 +1,112 @@
+"""Worker bodies for the world_size-2 tests of the multi-GPU host logic (spawned by torch.multiprocessing).
+
+`engine="oracle"` runs the per-shard compute on the CPU oracle (a TEST DOUBLE for the HIP engine, so the
+sharding / exchange / transcript logic is covered where there is no GPU); `engine="gpu"` uses the product's
+GpuShard (HIP kernels) with both ranks on cuda:0.  The process group is gloo in both cases; on a real
+multi-GPU node bench.py uses "nccl" (= RCCL)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class OracleShard:
+    """test double of zkmle_amd.sharded.GpuShard on the CPU oracle"""
+
+    def __init__(self, field, arr):
+        self.field, self.arr = field, np.ascontiguousarray(arr, np.uint64)
+
+    def spawn(self, arr):
+        return OracleShard(self.field, arr)
+
+    def __len__(self):
+        return self.arr.shape[0]
+
+    def half_sums(self):
+        from oracle import oracle as O
+        return O.split_and_sum(self.field, self.arr)
+
+    def fold(self, r):
+        from oracle import oracle as O
+        return OracleShard(self.field, O.partial_evaluate(self.field, self.arr, 0, r))
+
+    def fold_half_sums(self, r):
+        f = self.fold(r)
+        return f, f.half_sums()
+
+    def download(self):
+        return self.arr
+
+    def to_bytes(self):
+        from oracle import oracle as O
+        return O.mle_to_bytes(self.field, self.arr)
+
+
+class OracleSumShard:
+    def __init__(self, field, tabs):
+        self.field, self.tabs = field, np.ascontiguousarray(tabs, np.uint64)   # (nprod, nfac, len, limbs)
+        self.nprod, self.nfac = self.tabs.shape[0], self.tabs.shape[1]
+
+    def spawn(self, arrays):
+        return OracleSumShard(self.field, arrays)
+
+    def __len__(self):
+        return self.tabs.shape[2]
+
+    def round_evals(self):
+        from oracle import oracle as O
+        return O.gkr_round_univariate(self.field, self.tabs)
+
+    def fold(self, r):
+        from oracle import oracle as O
+        return OracleSumShard(self.field, np.stack([np.stack([O.partial_evaluate(self.field, t, 0, r) for t in prod]) for prod in self.tabs]))
+
+    def fold_round_evals(self, r):
+        f = self.fold(r)
+        return f, f.round_evals()
+
+    def download(self):
+        return self.tabs
+
+
+def run(rank, world, port, engine, field, table, sum_tables, claimed, scalars, points, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as G
+        zk = G.import_package()
+        S = zk.sharded
+        comm = S.Comm()
+        if engine == "gpu":
+            from zkmle_amd import _lib
+            _lib.check(zk.lib().zk_init(0))
+            mk = lambda a: S.GpuShard.from_array(field, a)
+            mk_sum = lambda a: S.GpuSumShard(field, [[zk.MultilinearPolynomial(field, t) for t in prod] for prod in a])
+        else:
+            mk = lambda a: OracleShard(field, a)
+            mk_sum = lambda a: OracleSumShard(field, a)
+        res = {}
+        cs, rp, ch = S.sumcheck_basic_prove(comm, mk(S.shard_of(table, rank, world)))
+        res.update(basic_claimed=cs, basic_rounds=rp, basic_chal=ch)
+        t = zk.Transcript()
+        t.append(b"prefix")
+        co, gch = S.sumcheck_gkr_prove(comm, mk_sum(sum_tables[:, :, rank::world]), claimed, t)
+        res.update(gkr_coeffs=co, gkr_chal=gch, gkr_tail=np.frombuffer(t.sample_random_challenge(), np.uint8))
+        if scalars is not None:
+            n = scalars.shape[0]
+            lo, hi = rank * n // world, (rank + 1) * n // world           # slice sharding of the MSM terms
+            if engine == "gpu":
+                local = lambda: zk.kzg.msm(zk.MultilinearPolynomial.vector(0, scalars[lo:hi]), zk.G1Bases(points[lo:hi]))
+            else:
+                from oracle import oracle as O
+                local = lambda: O.kzg_commit(scalars[lo:hi], points[lo:hi])
+            res["msm"] = S.msm(comm, local)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    finally:
+        dist.destroy_process_group()

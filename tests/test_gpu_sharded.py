@@ -1,0 +1,52 @@
+"""GPU: the multi-GPU provers with two ranks sharing cuda:0 (HIP kernels per shard, gloo exchange), and
+prove_succinct, bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as G
+from oracle import oracle as O
+
+from test_sharded_cpu import launch, expected, check, rand_table
+
+pytestmark = pytest.mark.gpu
+OPS = {"add": 0, "mul": 1}
+
+
+@pytest.mark.parametrize("world,logn", [(2, 2), (2, 10), (4, 9)])
+def test_sharded_provers_on_gpu(world, logn):
+    field = O.FR381
+    n = 1 << logn
+    table = rand_table(field, n, 20 + logn)
+    sum_tables = np.stack([np.stack([rand_table(field, n, 100 * p + 10 * f + logn) for f in range(2)]) for p in range(2)])
+    claimed = O.vec_sum(field, O.sumpoly_reduce(field, sum_tables))
+    g = O.g1_generator()
+    pts = np.stack([O.g1_mul_fr(g, O.from_ints(O.FR381, [7 + 3 * i])[0]) for i in range(16)])
+    scalars = rand_table(O.FR381, 16, 78)
+    results = launch(world, "gpu", field, table, sum_tables, claimed, scalars, pts)
+    want = expected(field, table, sum_tables, claimed)
+    want["msm"] = O.kzg_commit(scalars, pts)
+    check(results, want)
+
+
+def test_prove_succinct_reference_circuits(ref_kats):
+    zk = G.import_package()
+    from zkmle_amd import _lib
+    _lib.check(zk.lib().zk_init(0))
+    for k in ref_kats["succinct_gkr_roundtrip"]:              # succinct_gkr_protocol.rs:295-360
+        spec = k["layers"]
+        circuit = zk.Circuit.new(0, [zk.Layer.new([zk.Gate.new(g[0], g[1], g[2], OPS[g[3]]) for g in layer]) for layer in spec])
+        inputs = zk.from_ints(0, k["inputs"])
+        taus = zk.from_ints(0, k["taus"])
+        setup = zk.TrustedSetup.initialize_setup(taus)
+        proof = zk.gkr.prove_succinct(circuit, inputs, setup)
+        pts = O.kzg_setup_g1(taus)
+        layers = [[(g[0], g[1], g[2], OPS[g[3]]) for g in layer] for layer in spec]
+        want = O.gkr_prove_succinct(layers, inputs, pts)
+        assert np.array_equal(proof.claimed_sum, want["claimed_sum"])
+        assert np.array_equal(proof._flat[1], want["coeffs"])
+        assert np.array_equal(proof.input_polynomial_commitment, want["input_polynomial_commitment"])
+        for got, (ev, prs) in ((proof.input_rb_proof, want["input_rb_proof"]), (proof.input_rc_proof, want["input_rc_proof"])):
+            assert np.array_equal(got.evaluation, ev) and np.array_equal(got.proofs, prs)
+        # the opened values are the verifier's wb / wc of the input layer (succinct_gkr_protocol.rs:226-233)
+        ch = want["challenges"][-O.gkr_rounds(len(layers) - 1):]
+        assert np.array_equal(proof.input_rb_proof.evaluation, O.evaluate(O.FR381, inputs, ch[: len(ch) // 2]))

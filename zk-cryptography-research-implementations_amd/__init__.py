@@ -18,6 +18,7 @@ from . import gkr  # noqa: F401
 from .gkr import Circuit, Gate, Layer, Operator  # noqa: F401
 from . import kzg  # noqa: F401
 from .kzg import G1Bases, TrustedSetup, MultilinearKZG  # noqa: F401
+from . import sharded  # noqa: F401
 
 __all__ = ["MultilinearPolynomial", "FR381", "FQ381", "BN254_FQ", "BN254_FR", "ZkError", "ReferencePanic",
            "from_ints", "to_ints", "limbs", "lib", "library_path"]

@@ -25,6 +25,26 @@ int zk_fe_from_le_bytes_mod_order(int field, const uint8_t *bytes, size_t n, uin
     ZK_DISPATCH_FIELD(field, { Fe<F> e = host_from_le_bytes_mod_order<F>(bytes, n); memcpy(out, e.l, 4 * F::N); });
     return ZK_OK;
 }
+#define ZK_HOST_BINOP(name, expr)                                                          \
+    int name(int field, const uint64_t *a, const uint64_t *b, uint64_t *out) {             \
+        if (!a || !b || !out) return ZK_E_ARG;                                             \
+        ZK_DISPATCH_FIELD(field, {                                                         \
+            Fe<F> x, y;                                                                    \
+            memcpy(x.l, a, 4 * F::N);                                                      \
+            memcpy(y.l, b, 4 * F::N);                                                      \
+            Fe<F> o = expr;                                                                \
+            memcpy(out, o.l, 4 * F::N);                                                    \
+        });                                                                                \
+        return ZK_OK;                                                                      \
+    }
+ZK_HOST_BINOP(zk_fe_add, fe_add<F>(x, y))
+ZK_HOST_BINOP(zk_fe_sub, fe_sub<F>(x, y))
+ZK_HOST_BINOP(zk_fe_mul, fe_mul<F>(x, y))
+int zk_fe_inv(int field, const uint64_t *a, uint64_t *out) {
+    if (!a || !out) return ZK_E_ARG;
+    ZK_DISPATCH_FIELD(field, { Fe<F> x; memcpy(x.l, a, 4 * F::N); Fe<F> o = fe_inv<F>(x); memcpy(out, o.l, 4 * F::N); });
+    return ZK_OK;
+}
 int zk_vec_from_canonical(int field, const uint64_t *canon, size_t n, uint64_t *mont) {
     if (!canon || !mont) return ZK_E_ARG;
     ZK_DISPATCH_FIELD(field, {

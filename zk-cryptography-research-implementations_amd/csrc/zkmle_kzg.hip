@@ -286,6 +286,18 @@ int zk_g1_is_on_curve(const uint64_t *p12) {
     return g1_on_curve(affine_from_u64(p12)) ? 1 : 0;
 }
 
+int zk_g1_add(const uint64_t *p12, const uint64_t *q12, uint64_t *out12) {
+    if (!p12 || !q12 || !out12) return ZK_E_ARG;
+    affine_to_u64(g1_to_affine(g1_madd(g1_from_affine(affine_from_u64(p12)), affine_from_u64(q12))), out12);
+    return ZK_OK;
+}
+int zk_g1_mul_fr(const uint64_t *p12, const uint64_t *scalar_fr, uint64_t *out12) {
+    if (!p12 || !scalar_fr || !out12) return ZK_E_ARG;
+    Fe<Fr381> k = fe_to_canonical<Fr381>(load_el<Fr381>(scalar_fr));
+    affine_to_u64(g1_to_affine(g1_mul_canonical(affine_from_u64(p12), k.l, 8)), out12);
+    return ZK_OK;
+}
+
 int zk_g1_bases_synthetic(size_t n, const uint64_t *a_fr, const uint64_t *d_fr, zk_g1_bases **out) {
     if (!a_fr || !d_fr || !out || n == 0) return ZK_E_ARG;
     ZK_TRY(require_device());
@@ -412,6 +424,35 @@ int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg
     zk_table_free(nxt);
     zk_table_free(q);
     zk_kzg_opening_key_free(own);
+    return rc;
+}
+
+int zk_gkr_prove_succinct(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *inputs, size_t ninputs,
+                          const zk_g1_bases *g1_powers, size_t n_g2, uint64_t *circuit_output, size_t *output_len, uint64_t *claimed_sum,
+                          uint64_t *layer_claims, uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals,
+                          uint64_t *commitment12, uint64_t *rb_evaluation, uint64_t *rb_proofs, uint64_t *rc_evaluation,
+                          uint64_t *rc_proofs) {
+    if (!g1_powers || !commitment12 || !rb_evaluation || !rb_proofs || !rc_evaluation || !rc_proofs || nlayers == 0) return ZK_E_ARG;
+    zk_table *in = nullptr;
+    ZK_TRY(zk_table_upload(ZK_FR381, inputs, ninputs, &in));                    // MultilinearPolynomial::new(inputs) :41
+    int rc = zk_kzg_commit(in, g1_powers, commitment12);                         // :42-44
+    // the layer loop is gkr_protocol::prove's (same transcript schedule; rb / rc are taken from
+    // every layer's challenges here, :121-126, which only matters for the last layer's values)
+    if (rc == ZK_OK)
+        rc = zk_gkr_prove(ZK_FR381, gates, gate_counts, nlayers, inputs, ninputs, circuit_output, output_len, claimed_sum, layer_claims,
+                          coeffs, challenges, wb_evals, wc_evals);
+    if (rc == ZK_OK) {
+        size_t off = 0;
+        for (size_t L = 0; L + 1 < nlayers; L++) off += zk_gkr_rounds(L);
+        size_t rounds = zk_gkr_rounds(nlayers - 1), mid = rounds / 2;
+        const uint64_t *rb = challenges + off * 4, *rcv = challenges + (off + mid) * 4;
+        zk_kzg_opening_key *key = nullptr;
+        rc = (in->len == g1_powers->n) ? zk_kzg_opening_key_new(g1_powers, &key) : ZK_E_KZG_LEN;
+        if (rc == ZK_OK) rc = zk_kzg_open(in, g1_powers, key, rb, mid, n_g2, rb_evaluation, rb_proofs);            // :154-155
+        if (rc == ZK_OK) rc = zk_kzg_open(in, g1_powers, key, rcv, rounds - mid, n_g2, rc_evaluation, rc_proofs);  // :156-157
+        zk_kzg_opening_key_free(key);
+    }
+    zk_table_free(in);
     return rc;
 }
 

@@ -349,6 +349,33 @@ int zk_sumpoly_round_evals(const zk_table *const *tables, size_t nprod, size_t n
     ZK_DISPATCH_FIELD(tables[0]->field, return round_evals<F>(tables, nprod, nfac, out));
     return ZK_OK;
 }
+int zk_sumpoly_fold_round_evals(const zk_table *const *in, zk_table *const *out, size_t nprod, size_t nfac, const uint64_t *value,
+                                uint64_t *out_evals) {
+    ZK_TRY(check_sumpoly(in, nprod, nfac));
+    if (!out || !value || !out_evals) return ZK_E_ARG;
+    if (nprod < 2 || nfac < 2) return ZK_E_NEED_TWO;
+    size_t len = in[0]->len;
+    if (len < 4) return ZK_E_ARG;
+    for (size_t k = 0; k < nprod * nfac; k++)
+        if (!out[k] || out[k]->field != in[0]->field || out[k]->len < len / 2 || out[k]->dptr == in[k]->dptr) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(in[0]->field, {
+        const size_t esz = 4 * F::N, npts = nfac + 1;
+        SumPolyTables tabs{};
+        for (size_t k = 0; k < nprod * nfac; k++) { tabs.in[k] = in[k]->dptr; tabs.out[k] = out[k]->dptr; }
+        size_t q = len / 4;
+        int grid = reduce_grid_for(q);
+        void *part;
+        ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
+        void *res = (char *)part + esz * (size_t)grid * npts;
+        ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, load_el<F>(value), part, grid)));
+        finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, (int)npts, res);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpy(out_evals, res, esz * npts, hipMemcpyDeviceToHost));
+    });
+    for (size_t k = 0; k < nprod * nfac; k++) out[k]->len = len / 2;
+    return ZK_OK;
+}
 int zk_sumpoly_reduce(const zk_table *const *tables, size_t nprod, size_t nfac, zk_table *out) {
     ZK_TRY(check_sumpoly(tables, nprod, nfac));
     if (!out || out->field != tables[0]->field || out->len < tables[0]->len) return ZK_E_ARG;

@@ -168,3 +168,54 @@ def verify(circuit, proof, inputs):
     L.check(lib.zk_gkr_verify(f, gates, counts, nl, L.p64(x), x.shape[0], L.p64(outp), outp.shape[0], L.p64(claims),
                               L.p64(co), L.p64(wb), L.p64(wc), C.byref(ok)))
     return bool(ok.value)
+
+
+class SuccinctProof(Proof):                      # succinct_gkr_protocol.rs:22-32
+    def __init__(self, base, input_polynomial_commitment, input_rb_proof, input_rc_proof):
+        super().__init__(base.circuit_output, base.claimed_sum, base.sumcheck_proofs, base.wb_evaluations,
+                         base.wc_evaluations, _flat=base._flat)
+        self.input_polynomial_commitment = input_polynomial_commitment
+        self.input_rb_proof = input_rb_proof
+        self.input_rc_proof = input_rc_proof
+
+
+def prove_succinct(circuit, inputs, trusted_setup):
+    """succinct_gkr_protocol::prove_succinct :35-169 (BLS12-381 Fr)"""
+    from .kzg import MultilinearKZGProof, _decl as kzg_decl
+    lib = _decl()
+    kzg_decl()
+    if not getattr(lib, "_succ_declared", False):
+        u64p, sz, gp, szp = L.u64p, L.sz, C.POINTER(_Gate), C.POINTER(C.c_size_t)
+        lib.zk_gkr_prove_succinct.argtypes = [gp, szp, sz, u64p, sz, L.vp, sz, u64p, szp] + [u64p] * 11
+        lib.zk_gkr_prove_succinct.restype = C.c_int
+        lib._succ_declared = True
+    f = circuit.field
+    if f != L.FR381:
+        raise L.ZkError(L.ZK_E_ARG, "prove_succinct needs the pairing's scalar field (BLS12-381 Fr)")
+    gates, counts = circuit._flat()
+    x = np.ascontiguousarray(inputs, np.uint64).reshape(-1, 4)
+    nl = len(circuit.layers)
+    rounds = [lib.zk_gkr_rounds(i) for i in range(nl)]
+    tot = sum(rounds)
+    max_out = max([g.output_index for g in circuit.layers[0].gates] + [0]) + 1
+    out = np.zeros((max_out, 4), np.uint64)
+    olen = C.c_size_t()
+    cs = np.zeros(4, np.uint64)
+    claims = np.zeros((nl, 4), np.uint64)
+    co = np.zeros((tot, 3, 4), np.uint64)
+    ch = np.zeros((tot, 4), np.uint64)
+    wb = np.zeros((max(nl - 1, 1), 4), np.uint64)
+    wc = np.zeros((max(nl - 1, 1), 4), np.uint64)
+    commit = np.zeros(12, np.uint64)
+    rb_ev, rc_ev = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+    rb_pr, rc_pr = np.zeros((nl, 12), np.uint64), np.zeros((nl, 12), np.uint64)
+    L.check(lib.zk_gkr_prove_succinct(gates, counts, nl, L.p64(x), x.shape[0], trusted_setup.g1_powers_of_tau._h,
+                                      trusted_setup.n_g2_powers_of_tau, L.p64(out), C.byref(olen), L.p64(cs), L.p64(claims),
+                                      L.p64(co), L.p64(ch), L.p64(wb), L.p64(wc), L.p64(commit), L.p64(rb_ev), L.p64(rb_pr),
+                                      L.p64(rc_ev), L.p64(rc_pr)))
+    proofs, off = [], 0
+    for i, r in enumerate(rounds):
+        proofs.append(SumcheckProverProof(claims[i].copy(), co[off:off + r].copy(), ch[off:off + r].copy()))
+        off += r
+    base = Proof(out[: olen.value], cs, proofs, wb[: nl - 1], wc[: nl - 1], _flat=(claims, co, ch))
+    return SuccinctProof(base, commit, MultilinearKZGProof(rb_ev, rb_pr), MultilinearKZGProof(rc_ev, rc_pr))
