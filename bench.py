@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--log-n", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-msm", action="store_true", help="skip the secondary 2^log-n MSM measurement")
+    ap.add_argument("--msm-reps", type=int, default=3)
     args = ap.parse_args()
 
     import numpy as np
@@ -99,12 +101,87 @@ def main():
                      "traffic": None, "kernel": "fold_kernel<Fr381>", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": algo_bytes},
     }
+    pmc = os.path.join(ROOT, "profiles", "r1", "fold_2p24_pmc.json")
+    if args.log_n == 24 and os.path.exists(pmc):            # PMC passes are separate rocprofv3 runs (committed summary)
+        with open(pmc) as f:
+            result["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+        result["roofline"]["traffic_source"] = "profiles/r1/fold_2p24_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)"
+    if world > 1:
+        result["exchange"] = sumcheck_round_exchange(zk, table, out, r, world, local_rank)
+    if not args.no_msm:
+        result["msm"] = msm_leg(zk, args, rank, world, local_rank)
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(zk, field)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def sumcheck_round_exchange(zk, table, out, r, world, local_rank):
+    """The path's real exchange step: one fused sumcheck round (fold + half sums) per rank plus ONE
+    all-gather of the 2 partial sums over RCCL and the host reduction mod p.  Reported beside the fold metric."""
+    import time
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    S = zk.sharded
+    comm = S.Comm(device=torch.device("cuda", local_rank))
+    reps = 50
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        folded, sums = table.fold_half_sums(r)
+        g = comm.all_gather(sums)
+        tot = np.stack([S.fe_sum(table.field, g[:, 0]), S.fe_sum(table.field, g[:, 1])])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"what": "fused sumcheck round on a 2^24 shard + all-gather of 2 field elements per rank (RCCL) + host reduce",
+            "ms_per_round": dt * 1e3, "bytes_per_rank_per_round": 64, "collective": "all_gather", "backend": "nccl (RCCL)"}
+
+
+def msm_leg(zk, args, rank, world, local_rank):
+    """G1-add/s on the 2^log-n Pippenger MSM (BASELINE.json's second metric): one slice per rank, one
+    all-gather of `world` affine points, world-1 additions (no bandwidth-sized collective)."""
+    import time
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    n = 1 << args.log_n
+    a = zk.from_ints(0, [0x5EED0003 + rank])[0]
+    d = zk.from_ints(0, [0x9E3779B97F4A7C15])[0]
+    bases = zk.G1Bases.synthetic(n, a, d)                   # P_i = [a + i d] G, generated on the device
+    scalars = zk.MultilinearPolynomial.random(0, n, 0x5EED0003 + 97 * rank)
+    out, st = zk.kzg.msm(scalars, bases, 0, True)           # warm-up
+    S = zk.sharded
+    comm = S.Comm(device=torch.device("cuda", local_rank)) if world > 1 else None
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.msm_reps):
+        out, st = zk.kzg.msm(scalars, bases, 0, True)
+        stats.append(st)
+        if world > 1:
+            total = S.g1_sum(comm.all_gather(out))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / args.msm_reps
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    st = stats[-1]
+    W = st["windows"]
+    return {"metric": f"G1-add/s (2^{args.log_n} MSM)", "value": W * n * world / dt, "unit": "G1-add/s",
+            "terms_per_s": n * world / dt, "ms_per_msm": dt * 1e3, "window_bits": st["window_bits"], "windows": W,
+            "adds_per_term": W, "device_ms": {k: st[k] for k in ("ms_digits", "ms_sort", "ms_buckets", "ms_reduce", "ms_total")},
+            "bound": "integer VALU (v_mad_u64_u32), not HBM", "unique_bytes_per_term": 128,
+            "hbm_GBps_unique": 128.0 * n / (st["ms_total"] * 1e-3) / 1e9,
+            "workload": f"2^{args.log_n} random Fr scalars x synthetic affine bases [a + i d]G per GPU; slice-sharded, all-gather of {world} points"}
 
 
 def cpu_baseline(zk, field):
