@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../zk-cryptography-research-implementations_amd/csrc/mle_kernels.cuh"
+#include "../zk-cryptography-research-implementations_amd/csrc/ufield.cuh"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -48,6 +49,26 @@ template <class F, int MULS> __global__ void k_mont_chain(void *out, uint64_t se
     zk::Fe<F> x = zk::random_element<F>(seed, gid), y = zk::random_element<F>(seed + 1, gid);
     for (int i = 0; i < MULS; i++) x = zk::fe_mul<F>(x, y);
     zk::fe_store<F>(out, gid, x);
+}
+// unsaturated 29-bit-limb chain: x <- x*y in the internal form
+template <class F, int MULS> __global__ void k_umul_chain(void *out, uint64_t seed) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    zk::Ufe<F> x = zk::u_from_limbs32<F>(zk::random_element<F>(seed, gid)), y = zk::u_from_limbs32<F>(zk::random_element<F>(seed + 1, gid));
+    for (int i = 0; i < MULS; i++) x = zk::umul<F>(x, y);
+    zk::fe_store<F>(out, gid, zk::u_to_limbs32<F>(x));
+}
+// drop-in product through the unsaturated scan (conversions included)
+template <class F, int MULS> __global__ void k_mulu_chain(void *out, uint64_t seed) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    zk::Fe<F> x = zk::random_element<F>(seed, gid), y = zk::random_element<F>(seed + 1, gid);
+    for (int i = 0; i < MULS; i++) x = zk::fe_mul_u<F>(x, y);
+    zk::fe_store<F>(out, gid, x);
+}
+template <class F> __global__ void k_fold_u(const void *__restrict__ in, void *__restrict__ out, size_t half, zk::Ufe<F> ru) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    zk::Fe<F> lo = zk::fe_load<F>(in, i), hi = zk::fe_load<F>(in, i + half);
+    zk::fe_store<F>(out, i, zk::fe_add<F>(lo, zk::fe_mul_u_pre<F>(ru, zk::fe_sub<F>(hi, lo))));
 }
 // the fold's memory pattern with trivial arithmetic (2 streams in, 1 out, 32 B per lane)
 template <class F> __global__ void k_stream3(const void *in, void *out, size_t half) {
@@ -153,6 +174,12 @@ int main(int argc, char **argv) {
         printf("{\"kernel\": \"mont_chain_fr381\", \"ms\": %.4f, \"field_mul_per_s\": %.4e}\n", ms, lanes * MULS / (ms * 1e-3));
         ms = time_ms([&] { k_mont_chain<zk::Fq381, MULS><<<blocks, threads>>>(buf, 7); }, 5);
         printf("{\"kernel\": \"mont_chain_fq381\", \"ms\": %.4f, \"field_mul_per_s\": %.4e}\n", ms, lanes * MULS / (ms * 1e-3));
+        ms = time_ms([&] { k_umul_chain<zk::Fr381, MULS><<<blocks, threads>>>(buf, 7); }, 5);
+        printf("{\"kernel\": \"umul_chain_fr381\", \"ms\": %.4f, \"field_mul_per_s\": %.4e}\n", ms, lanes * MULS / (ms * 1e-3));
+        ms = time_ms([&] { k_umul_chain<zk::Fq381, MULS><<<blocks, threads>>>(buf, 7); }, 5);
+        printf("{\"kernel\": \"umul_chain_fq381\", \"ms\": %.4f, \"field_mul_per_s\": %.4e}\n", ms, lanes * MULS / (ms * 1e-3));
+        ms = time_ms([&] { k_mulu_chain<zk::Fr381, MULS><<<blocks, threads>>>(buf, 7); }, 5);
+        printf("{\"kernel\": \"fe_mul_u_chain_fr381\", \"ms\": %.4f, \"field_mul_per_s\": %.4e}\n", ms, lanes * MULS / (ms * 1e-3));
         CK(hipFree(buf));
     }
     // streaming: 2^24-element Fr table (512 MiB) -> 2^23
@@ -181,6 +208,12 @@ int main(int argc, char **argv) {
                 float ms = time_ms([&] { k_fold_v<zk::Fr381, EPT, NT><<<grid, BS>>>(in, out, half, r); }, 20); \
                 printf("{\"kernel\": \"fold_v\", \"ept\": %d, \"nt\": %d, \"block\": %d, \"grid\": %d, \"ms\": %.4f, \"GBps\": %.1f}\n", EPT, (int)NT, BS, grid, ms, 96.0 * half / (ms * 1e-3) / 1e9); \
                 fflush(stdout);                                                                             \
+            }
+            {
+                zk::Ufe<zk::Fr381> ru = zk::u_from_limbs32<zk::Fr381>(r);
+                int grid = (int)((half + 255) / 256);
+                float ms = time_ms([&] { k_fold_u<zk::Fr381><<<grid, 256>>>(in, out, half, ru); }, 20);
+                printf("{\"kernel\": \"fold_u29\", \"grid\": %d, \"ms\": %.4f, \"GBps\": %.1f}\n", grid, ms, 96.0 * half / (ms * 1e-3) / 1e9);
             }
             RUN_V(1, false, 256) RUN_V(1, false, 512) RUN_V(1, false, 1024) RUN_V(1, false, 128) RUN_V(1, false, 64)
             RUN_V(2, false, 256) RUN_V(4, false, 256) RUN_V(2, false, 128) RUN_V(2, false, 512)

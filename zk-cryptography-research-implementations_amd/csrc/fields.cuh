@@ -171,9 +171,9 @@ template <class F> ZK_HD Fe<F> fe_neg(const Fe<F> &a) { return fe_sub<F>(fe_zero
 
 template <class F> ZK_HD Fe<F> fe_dbl(const Fe<F> &a) { return fe_add<F>(a, a); }
 
-// CIOS Montgomery product a*b*R^-1 mod p, fully reduced.  All four moduli leave the top bit of
+// Saturated CIOS Montgomery product a*b*R^-1 mod p, fully reduced (host path; on the device see ufield.cuh).  All four moduli leave the top bit of
 // the top limb clear, so the running value stays below 2p and t[N] never overflows 32 bits.
-template <class F> ZK_HD Fe<F> fe_mul(const Fe<F> &a, const Fe<F> &b) {
+template <class F> ZK_HD Fe<F> fe_mul_cios(const Fe<F> &a, const Fe<F> &b) {
     constexpr int N = F::N;
     uint32_t t[N + 1];
 #pragma unroll
@@ -208,42 +208,8 @@ template <class F> ZK_HD Fe<F> fe_mul(const Fe<F> &a, const Fe<F> &b) {
     return r;
 }
 
-template <class F> ZK_HD Fe<F> fe_sqr(const Fe<F> &a) { return fe_mul<F>(a, a); }
-
-// Montgomery form -> canonical integer (into_bigint()): multiply by the raw integer 1
-template <class F> ZK_HD Fe<F> fe_to_canonical(const Fe<F> &a) {
-    Fe<F> one = fe_zero<F>();
-    one.l[0] = 1;
-    return fe_mul<F>(a, one);
-}
-template <class F> ZK_HD Fe<F> fe_from_canonical(const Fe<F> &c) {
-    Fe<F> r2;
-#pragma unroll
-    for (int i = 0; i < F::N; i++) r2.l[i] = F::r2(i);
-    return fe_mul<F>(c, r2);
-}
-template <class F> ZK_HD Fe<F> fe_from_u64(uint64_t v) {
-    Fe<F> c = fe_zero<F>();
-    c.l[0] = (uint32_t)v;
-    c.l[1] = (uint32_t)(v >> 32);
-    return fe_from_canonical<F>(c);
-}
-
-// a^(p-2); host-side helper (Lagrange interpolation, batch normalisation)
-template <class F> ZK_HD Fe<F> fe_inv(const Fe<F> &a) {
-    Fe<F> acc = fe_one<F>(), base = a;
-    uint32_t borrow = 2;   // exponent p - 2, computed limb by limb
-    for (int i = 0; i < F::N; i++) {
-        uint32_t pi = F::p(i);
-        uint32_t e = pi - borrow;
-        borrow = (pi < borrow) ? 1u : 0u;
-        for (int k = 0; k < 32; k++) {
-            if ((e >> k) & 1) acc = fe_mul<F>(acc, base);
-            base = fe_sqr<F>(base);
-        }
-    }
-    return acc;
-}
+// fe_mul / fe_sqr / fe_inv / canonical conversions are defined in ufield.cuh (the device product is the
+// unsaturated 29-bit scan; fe_mul_cios above is the saturated reference form used on the host).
 
 // ---- 16-byte vector load / store of an element (N/4 x dwordx4, coalesced across lanes) ----------
 template <class F> __device__ __forceinline__ Fe<F> fe_load(const void *base, size_t idx) {

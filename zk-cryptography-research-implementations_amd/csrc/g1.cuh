@@ -10,7 +10,7 @@
 // (infinity operands, P = Q, P = -Q) so results are exact for any input, including repeated and
 // infinite bases (SURVEY.md 7 "MSM exactness").
 #pragma once
-#include "fields.cuh"
+#include "ufield.cuh"
 
 namespace zk {
 

@@ -1,0 +1,116 @@
+// g1u.cuh -- the Pippenger bucket update in the unsaturated (14 x 29-bit limb) Fq representation.
+//
+// Same group law as g1.cuh's madd-2008-s, rearranged so that every subtrahend is a product (< 2 p)
+// or a doubled product (< 4 p): with P' = X1 - U2 and R' = Y1 - S2 (the negated differences)
+//     PP = P'^2, PPP' = P' PP, Q = X1 PP,
+//     X3 = R'^2 + PPP' - 2 Q,   Y3 = R' (X3 - Q) + Y1 PPP',   ZZ3 = ZZ1 PP,   ZZZ3 = -(ZZZ1 PPP').
+// No value ever needs a modular reduction (inputs of a product may be any representative below
+// 2^12 p; accumulator coordinates stay below 8 p), additions are plain limb adds with one carry
+// pass, and the exceptional cases (P = Q, P = -Q) are detected AFTER the fact from ZZ3 = 0 mod p
+// and redone exactly on a rare slow path.  Bases are stored pre-converted (2 x 16 words = one
+// 128-byte line per point); results leave the kernel in the stored XYZZ form of g1.cuh.
+#pragma once
+#include "g1.cuh"
+
+namespace zk {
+
+using FqU = Ufe<Fq381>;
+constexpr int kUWords = 16;                         // 14 limbs + 2 pad words: 64 B per coordinate
+
+struct G1AffineU { FqU x, y; };
+struct G1XyzzU { FqU x, y, zz, zzz; bool inf; };
+
+ZK_HD FqU fqu_one() {                               // the internal Montgomery one: 2^(29 L) mod p
+    FqU r;
+#pragma unroll
+    for (int j = 0; j < UParams<Fq381>::L; j++) r.l[j] = UParams<Fq381>::r_u(j);
+    return r;
+}
+ZK_HD FqU fqu_renorm(const FqU &a) { return umul<Fq381>(a, fqu_one()); }      // any representative -> (< 2 p)
+ZK_HD bool fqu_is_zero(const FqU &a) { return u_is_zero_mod_p<Fq381>(fqu_renorm(a)); }
+
+__device__ __forceinline__ FqU fqu_load(const uint32_t *p) {
+    FqU r;
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w; r.l[12] = d.x; r.l[13] = d.y;
+    return r;
+}
+__device__ __forceinline__ void fqu_store(uint32_t *p, const FqU &v) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+    q[3] = make_uint4(v.l[12], v.l[13], 0u, 0u);
+}
+__device__ __forceinline__ G1AffineU g1u_load_affine(const void *base, size_t idx) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(base) + idx * (2 * kUWords);
+    G1AffineU r;
+    r.x = fqu_load(p);
+    r.y = fqu_load(p + kUWords);
+    return r;
+}
+
+// exact doubling of an affine point, all in the internal form (rare path)
+__device__ __forceinline__ void g1u_mdbl(G1XyzzU &o, const G1AffineU &q) {
+    using F = Fq381;
+    FqU u = uadd<F>(q.y, q.y);
+    FqU v = usqr<F>(u);
+    FqU w = umul<F>(u, v);
+    FqU s = umul<F>(q.x, v);
+    FqU xx = usqr<F>(q.x);
+    FqU m = uadd<F>(uadd<F>(xx, xx), xx);
+    FqU x3 = fqu_renorm(usub<F>(usqr<F>(m), uadd<F>(s, s)));      // < 2 p again
+    o.x = x3;
+    o.y = usub<F>(umul<F>(m, usub<F>(s, x3)), umul<F>(w, q.y));
+    o.zz = v;
+    o.zzz = w;
+    o.inf = false;
+}
+
+// acc += q  (q finite or the exact-zero infinity encoding; `neg` adds -q)
+__device__ __forceinline__ void g1u_madd(G1XyzzU &acc, G1AffineU q, bool neg) {
+    using F = Fq381;
+    if (u_is_exact_zero<F>(q.x) && u_is_exact_zero<F>(q.y)) return;           // base at infinity
+    if (neg) q.y = usub<F>(u_zero<F>(), q.y);                                  // 4 p - y
+    if (acc.inf) {
+        acc.x = q.x; acc.y = q.y; acc.zz = fqu_one(); acc.zzz = fqu_one(); acc.inf = false;
+        return;
+    }
+    FqU u2 = umul<F>(q.x, acc.zz);
+    FqU s2 = umul<F>(q.y, acc.zzz);
+    FqU pn = usub<F>(acc.x, u2);                       // P' = X1 - U2
+    FqU rn = usub<F>(acc.y, s2);                       // R' = Y1 - S2
+    FqU pp = usqr<F>(pn);
+    FqU pppn = umul<F>(pn, pp);                        // PPP' = -PPP
+    FqU qq = umul<F>(acc.x, pp);
+    FqU zz3 = umul<F>(acc.zz, pp);
+    if (u_is_zero_mod_p<F>(zz3)) {                     // P = 0 (or ZZ1 = 0 mod p): exceptional, redo exactly
+        if (fqu_is_zero(pn)) {
+            if (fqu_is_zero(rn)) g1u_mdbl(acc, q);     // acc == q
+            else { acc.inf = true; acc.x = u_zero<F>(); acc.y = u_zero<F>(); acc.zz = u_zero<F>(); acc.zzz = u_zero<F>(); }
+            return;
+        }
+    }
+    FqU x3 = usub<F>(uadd<F>(usqr<F>(rn), pppn), uadd<F>(qq, qq));
+    FqU y3 = uadd<F>(umul<F>(rn, usub<F>(x3, qq)), umul<F>(acc.y, pppn));
+    acc.zzz = usub<F>(u_zero<F>(), umul<F>(acc.zzz, pppn));
+    acc.zz = zz3;
+    acc.x = x3;
+    acc.y = y3;
+}
+
+// internal accumulator -> stored XYZZ (canonical 32-bit Montgomery limbs)
+__device__ __forceinline__ G1Xyzz g1u_to_std(const G1XyzzU &a) {
+    using F = Fq381;
+    if (a.inf) return g1_xyzz_inf();
+    G1Xyzz r;
+    r.x = u_to_std<F>(a.x);
+    r.y = u_to_std<F>(a.y);
+    r.zz = u_to_std<F>(a.zz);
+    r.zzz = u_to_std<F>(a.zzz);
+    return r;
+}
+
+}  // namespace zk

@@ -3,7 +3,7 @@
 //   to_bytes_le : into_bigint().to_bytes_le()  sumcheck_gkr_protocol.rs:148
 //   from_le_bytes_mod_order : fiat_shamir_transcript.rs:42 [ark-ff]
 #pragma once
-#include "fields.cuh"
+#include "ufield.cuh"
 
 namespace zk {
 

@@ -7,7 +7,7 @@
 // :49-57 / :108-163 (element-wise and tensor ops), sumcheck_protocol/src/basic_sumcheck/prover.rs:74-89
 // (half sums).
 #pragma once
-#include "fields.cuh"
+#include "ufield.cuh"
 
 namespace zk {
 
@@ -46,6 +46,13 @@ template <class F> __global__ void fill_random_kernel(void *out, size_t len, uin
         fe_store<F>(out, i, random_element<F>(seed, first + i));
 }
 
+// a loop-invariant multiplier (the round challenge r): converted once per lane to the 29-bit form
+template <class F> struct Multiplier {
+    Ufe<F> u;
+    __device__ __forceinline__ explicit Multiplier(const Fe<F> &r) : u(u_from_limbs32<F>(r)) {}
+    __device__ __forceinline__ Fe<F> times(const Fe<F> &x) const { return fe_mul_u_pre<F>(u, x); }
+};
+
 // ---- fold: out[i] = y1 + r * (y2 - y1)   evaluation_form.rs:88-89 -----------------------------------
 // `power` = n - 1 - var (:80).  Output index i maps to y1 index j = i with a zero bit inserted
 // at position `power` (the reference's j-walk :98-102), y2 = j | 1<<power (:82).
@@ -53,11 +60,12 @@ template <class F> __global__ void fold_kernel(const void *__restrict__ in, void
                                               size_t half, unsigned power, Fe<F> r) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t lowmask = ((size_t)1 << power) - 1;
+    const Multiplier<F> mr(r);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
         size_t j = ((i & ~lowmask) << 1) | (i & lowmask);
         Fe<F> y1 = fe_load<F>(in, j);
         Fe<F> y2 = fe_load<F>(in, j | ((size_t)1 << power));
-        fe_store<F>(out, i, fe_add<F>(y1, fe_mul<F>(r, fe_sub<F>(y2, y1))));
+        fe_store<F>(out, i, fe_add<F>(y1, mr.times(fe_sub<F>(y2, y1))));
     }
 }
 
@@ -122,11 +130,12 @@ template <class F> __global__ void fold_half_sums_kernel(const void *__restrict_
     __shared__ Fe<F> sh[kBlock / 64];
     size_t stride = (size_t)gridDim.x * blockDim.x;
     Fe<F> s0 = fe_zero<F>(), s1 = fe_zero<F>();
+    const Multiplier<F> mr(r);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
         Fe<F> a0 = fe_load<F>(in, i), a1 = fe_load<F>(in, i + q);
         Fe<F> b0 = fe_load<F>(in, i + 2 * q), b1 = fe_load<F>(in, i + 3 * q);
-        Fe<F> o0 = fe_add<F>(a0, fe_mul<F>(r, fe_sub<F>(b0, a0)));
-        Fe<F> o1 = fe_add<F>(a1, fe_mul<F>(r, fe_sub<F>(b1, a1)));
+        Fe<F> o0 = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
+        Fe<F> o1 = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
         fe_store<F>(out, i, o0);
         fe_store<F>(out, i + q, o1);
         s0 = fe_add<F>(s0, o0);

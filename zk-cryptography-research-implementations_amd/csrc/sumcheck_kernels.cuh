@@ -87,6 +87,7 @@ __global__ void fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q,
 #pragma unroll
     for (int t = 0; t <= NFAC; t++) acc[t] = fe_zero<F>();
     size_t stride = (size_t)gridDim.x * blockDim.x;
+    const Multiplier<F> mr(r);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
         for (int p = 0; p < nprod; p++) {
             Fe<F> lo[NFAC], hi[NFAC];
@@ -96,8 +97,8 @@ __global__ void fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q,
                 void *dst = tabs.out[p * NFAC + f];
                 Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
                 Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
-                lo[f] = fe_add<F>(a0, fe_mul<F>(r, fe_sub<F>(b0, a0)));
-                hi[f] = fe_add<F>(a1, fe_mul<F>(r, fe_sub<F>(b1, a1)));
+                lo[f] = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
+                hi[f] = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
                 fe_store<F>(dst, i, lo[f]);
                 fe_store<F>(dst, i + q, hi[f]);
             }
@@ -111,10 +112,11 @@ __global__ void fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q,
 template <class F>
 __global__ void fold_all_kernel(SumPolyTables tabs, int ntab, size_t half, Fe<F> r) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
+    const Multiplier<F> mr(r);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride)
         for (int k = 0; k < ntab; k++) {
             Fe<F> y1 = fe_load<F>(tabs.in[k], i), y2 = fe_load<F>(tabs.in[k], i + half);
-            fe_store<F>(tabs.out[k], i, fe_add<F>(y1, fe_mul<F>(r, fe_sub<F>(y2, y1))));
+            fe_store<F>(tabs.out[k], i, fe_add<F>(y1, mr.times(fe_sub<F>(y2, y1))));
         }
 }
 

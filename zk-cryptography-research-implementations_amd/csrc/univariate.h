@@ -4,7 +4,7 @@
 #pragma once
 #include <vector>
 
-#include "fields.cuh"
+#include "ufield.cuh"
 
 namespace zk {
 

@@ -3,7 +3,7 @@
 #include <string.h>
 
 #include "context.h"
-#include "fields.cuh"
+#include "ufield.cuh"
 #include "host_field.h"
 
 using namespace zk;

@@ -15,7 +15,8 @@ using namespace zk;
 
 struct zk_g1_bases {
     size_t n;
-    void *dptr;   // n affine points, 96 B each
+    void *dptr;            // n affine points, 96 B each (stored Montgomery form: what upload / download see)
+    void *dptr_u = nullptr; // the same points pre-converted for the bucket kernel (128 B each), built on first use
 };
 struct zk_kzg_opening_key {
     // level[t] (t = 1..nvars): 2^(nvars - t) pre-summed affine bases B^(t)_k = sum_{h < 2^t} B_{h 2^(nvars-t) + k}
@@ -62,8 +63,12 @@ int pick_window(size_t n) {
     return c < 4 ? 4 : c;
 }
 
+int bases_u(const zk_g1_bases *b, const void **out);
+
 // sum_i [s_i] B_i ; result as XYZZ on the host
-int msm_device(const void *d_scalars, const void *d_bases, size_t n, int c, G1Xyzz *result, zk_msm_stats *stats) {
+int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c, G1Xyzz *result, zk_msm_stats *stats) {
+    const void *d_bases = nullptr;
+    ZK_TRY(bases_u(bases, &d_bases));                       // pre-converted points (cached on the handle)
     if (c == 0) c = pick_window(n);
     if (c < 2 || c > 16) return ZK_E_ARG;
     if (n >= ((size_t)1 << 31)) return ZK_E_ARG;            // index + sign are packed in 32 bits
@@ -173,7 +178,19 @@ int msm_device(const void *d_scalars, const void *d_bases, size_t n, int c, G1Xy
 int bases_alloc(size_t n, zk_g1_bases **out) {
     void *d = nullptr;
     ZK_HIP(hipMalloc(&d, n * sizeof(G1Affine)));
-    *out = new zk_g1_bases{n, d};
+    *out = new zk_g1_bases{n, d, nullptr};
+    return ZK_OK;
+}
+int bases_u(const zk_g1_bases *b, const void **out) {
+    zk_g1_bases *mb = const_cast<zk_g1_bases *>(b);          // a cache of the same immutable points
+    if (!mb->dptr_u) {
+        void *d = nullptr;
+        ZK_HIP(hipMalloc(&d, b->n * kBaseUBytes));
+        int rc = launch_g1_bases_to_u(b->dptr, b->n, d, nullptr);
+        if (rc != ZK_OK) { (void)hipFree(d); return rc; }
+        mb->dptr_u = d;
+    }
+    *out = mb->dptr_u;
     return ZK_OK;
 }
 
@@ -271,6 +288,7 @@ int zk_g1_bases_download(const zk_g1_bases *b, uint64_t *affine) {
 int zk_g1_bases_free(zk_g1_bases *b) {
     if (!b) return ZK_OK;
     if (b->dptr) ZK_HIP(hipFree(b->dptr));
+    if (b->dptr_u) ZK_HIP(hipFree(b->dptr_u));
     delete b;
     return ZK_OK;
 }
@@ -316,7 +334,7 @@ int zk_msm_g1(const zk_table *scalars, const zk_g1_bases *bases, int window_bits
     if (scalars->len != bases->n) return ZK_E_KZG_LEN;
     ZK_TRY(require_device());
     G1Xyzz r;
-    ZK_TRY(msm_device(scalars->dptr, bases->dptr, scalars->len, window_bits, &r, stats));
+    ZK_TRY(msm_device(scalars->dptr, bases, scalars->len, window_bits, &r, stats));
     affine_to_u64(g1_to_affine(r), out12);
     return ZK_OK;
 }
@@ -413,7 +431,7 @@ int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg
         q->len = half;
         // proof_i = sum_j [blown_up(q)[j]] B_j  (:96-107)  ==  sum_k [q[k]] B^(i+1)_k
         G1Xyzz pi;
-        rc = msm_device(q->dptr, key->level[i + 1]->dptr, half, 0, &pi, nullptr);
+        rc = msm_device(q->dptr, key->level[i + 1], half, 0, &pi, nullptr);
         if (rc != ZK_OK) break;
         affine_to_u64(g1_to_affine(pi), proofs + 12 * i);
         nxt->len = half;
