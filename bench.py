@@ -98,7 +98,7 @@ def main():
                                f"2^{args.log_n}-entry table per GPU", "log_n": args.log_n, "field": "bls12_381_fr",
                    "sharding": "low-bit shard per rank, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "kernel": "fold_kernel<Fr381>", "kernel_ms": kern_ms,
+                     "traffic": None, "kernel": "fold0_kernel<Fr381>", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": algo_bytes},
     }
     pmc = os.path.join(ROOT, "profiles", "r1", "fold_2p24_pmc.json")

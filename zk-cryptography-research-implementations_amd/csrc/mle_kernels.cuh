@@ -69,6 +69,16 @@ template <class F> __global__ void fold_kernel(const void *__restrict__ in, void
     }
 }
 
+// variable 0 (the only variable production callers fold): two contiguous input streams,
+// one output element per lane, no index arithmetic
+template <class F> __global__ void fold0_kernel(const void *__restrict__ in, void *__restrict__ out, size_t half, Fe<F> r) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const Multiplier<F> mr(r);
+    Fe<F> y1 = fe_load<F>(in, i), y2 = fe_load<F>(in, i + half);
+    fe_store<F>(out, i, fe_add<F>(y1, mr.times(fe_sub<F>(y2, y1))));
+}
+
 // ---- reductions ------------------------------------------------------------------------------------
 template <class F> __device__ __forceinline__ Fe<F> wave_reduce_add(Fe<F> v) {
 #pragma unroll

@@ -217,7 +217,12 @@ int zk_mle_fold_ptr(int field, const void *d_in, size_t len, size_t var, const u
     size_t half = len / 2;
     unsigned power = n - 1 - (unsigned)var;
     hipStream_t s = (hipStream_t)stream;
-    ZK_DISPATCH_FIELD(field, (fold_kernel<F><<<grid_for(half), kBlock, 0, s>>>(d_in, d_out, half, power, load_host<F>(value))));
+    if (var == 0 && (half + kBlock - 1) / kBlock <= (size_t)0x7fffffff) {
+        unsigned grid = (unsigned)((half + kBlock - 1) / kBlock);
+        ZK_DISPATCH_FIELD(field, (fold0_kernel<F><<<grid, kBlock, 0, s>>>(d_in, d_out, half, load_host<F>(value))));
+    } else {
+        ZK_DISPATCH_FIELD(field, (fold_kernel<F><<<grid_for(half), kBlock, 0, s>>>(d_in, d_out, half, power, load_host<F>(value))));
+    }
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
