@@ -91,49 +91,69 @@ __global__ void msm_chunk_scan_kernel(uint32_t *__restrict__ hist, unsigned nwin
     totals[id] = run;
 }
 
-// pass 2b (one block): exclusive scans over all (w, b) of the entry counts and of the segment
-// counts ceil(count / seg_len).  starts[count] / seg_starts[count] hold the grand totals.
-__global__ void msm_bucket_scan_kernel(const uint32_t *__restrict__ totals, size_t count, unsigned seg_len,
-                                       uint64_t *__restrict__ starts, uint32_t *__restrict__ seg_starts) {
-    // seg_starts[count + 1] receives the largest per-bucket segment count
-    __shared__ uint64_t sh_e[kSortBlock];
-    __shared__ uint32_t sh_s[kSortBlock];
-    __shared__ uint32_t sh_m[kSortBlock];
-    size_t per = (count + blockDim.x - 1) / blockDim.x;
-    size_t lo = (size_t)threadIdx.x * per, hi = lo + per < count ? lo + per : count;
-    uint64_t se = 0;
-    uint32_t ss = 0, mx = 0;
-    for (size_t i = lo; i < hi; i++) {
-        uint32_t segs = (totals[i] + seg_len - 1) / seg_len;
-        se += totals[i];
-        ss += segs;
-        mx = segs > mx ? segs : mx;
+// pass 2b: exclusive scans over all (w, b) of the entry counts and of the segment counts
+// ceil(count / seg_len), as three coalesced kernels: per-tile totals, scan of the tile totals (one block),
+// per-tile scan + offset.  starts[count] / seg_starts[count] hold the grand totals and
+// seg_starts[count + 1] the largest per-bucket segment count.
+constexpr int kScanTile = 1024;
+__global__ void msm_scan_tiles_kernel(const uint32_t *__restrict__ totals, size_t count, unsigned seg_len,
+                                      uint64_t *__restrict__ tile_e, uint32_t *__restrict__ tile_s, uint32_t *__restrict__ tile_m) {
+    __shared__ uint64_t sh_e[kScanTile / 64];
+    __shared__ uint32_t sh_s[kScanTile / 64], sh_m[kScanTile / 64];
+    size_t i = (size_t)blockIdx.x * kScanTile + threadIdx.x;
+    uint32_t v = i < count ? totals[i] : 0u;
+    uint32_t segs = (v + seg_len - 1) / seg_len;
+    uint64_t e = v;
+    uint32_t s = segs, m = segs;
+    for (int off = 32; off >= 1; off >>= 1) {
+        e += __shfl_down(e, off, 64);
+        s += __shfl_down(s, off, 64);
+        uint32_t om = __shfl_down(m, off, 64);
+        m = om > m ? om : m;
     }
-    sh_e[threadIdx.x] = se;
-    sh_s[threadIdx.x] = ss;
-    sh_m[threadIdx.x] = mx;
+    if ((threadIdx.x & 63) == 0) { sh_e[threadIdx.x >> 6] = e; sh_s[threadIdx.x >> 6] = s; sh_m[threadIdx.x >> 6] = m; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint64_t re = 0;
-        uint32_t rs = 0, rm = 0;
-        for (unsigned t = 0; t < blockDim.x; t++) {
-            uint64_t ve = sh_e[t]; uint32_t vs = sh_s[t];
-            sh_e[t] = re; sh_s[t] = rs;
-            re += ve; rs += vs;
-            rm = sh_m[t] > rm ? sh_m[t] : rm;
-        }
-        starts[count] = re;
-        seg_starts[count] = rs;
-        seg_starts[count + 1] = rm;
+        uint64_t te = 0; uint32_t ts = 0, tm = 0;
+        for (int w = 0; w < kScanTile / 64; w++) { te += sh_e[w]; ts += sh_s[w]; tm = sh_m[w] > tm ? sh_m[w] : tm; }
+        tile_e[blockIdx.x] = te; tile_s[blockIdx.x] = ts; tile_m[blockIdx.x] = tm;
     }
+}
+__global__ void msm_scan_tile_totals_kernel(uint64_t *__restrict__ tile_e, uint32_t *__restrict__ tile_s, const uint32_t *__restrict__ tile_m,
+                                            unsigned ntiles, size_t count, uint64_t *__restrict__ starts, uint32_t *__restrict__ seg_starts) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;     // ntiles <= a few thousand: one lane is enough
+    uint64_t re = 0; uint32_t rs = 0, rm = 0;
+    for (unsigned t = 0; t < ntiles; t++) {
+        uint64_t ve = tile_e[t]; uint32_t vs = tile_s[t];
+        tile_e[t] = re; tile_s[t] = rs;
+        re += ve; rs += vs;
+        rm = tile_m[t] > rm ? tile_m[t] : rm;
+    }
+    starts[count] = re;
+    seg_starts[count] = rs;
+    seg_starts[count + 1] = rm;
+}
+__global__ void msm_scan_apply_kernel(const uint32_t *__restrict__ totals, size_t count, unsigned seg_len,
+                                      const uint64_t *__restrict__ tile_e, const uint32_t *__restrict__ tile_s,
+                                      uint64_t *__restrict__ starts, uint32_t *__restrict__ seg_starts) {
+    __shared__ uint64_t sh_e[kScanTile];
+    __shared__ uint32_t sh_s[kScanTile];
+    size_t i = (size_t)blockIdx.x * kScanTile + threadIdx.x;
+    uint32_t v = i < count ? totals[i] : 0u;
+    sh_e[threadIdx.x] = v;
+    sh_s[threadIdx.x] = (v + seg_len - 1) / seg_len;
     __syncthreads();
-    se = sh_e[threadIdx.x];
-    ss = sh_s[threadIdx.x];
-    for (size_t i = lo; i < hi; i++) {
-        starts[i] = se;
-        seg_starts[i] = ss;
-        se += totals[i];
-        ss += (totals[i] + seg_len - 1) / seg_len;
+    for (int off = 1; off < kScanTile; off <<= 1) {      // Hillis-Steele inclusive scan of the tile
+        uint64_t ae = threadIdx.x >= (unsigned)off ? sh_e[threadIdx.x - off] : 0;
+        uint32_t as = threadIdx.x >= (unsigned)off ? sh_s[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh_e[threadIdx.x] += ae;
+        sh_s[threadIdx.x] += as;
+        __syncthreads();
+    }
+    if (i < count) {
+        starts[i] = tile_e[blockIdx.x] + sh_e[threadIdx.x] - v;
+        seg_starts[i] = tile_s[blockIdx.x] + sh_s[threadIdx.x] - (v + seg_len - 1) / seg_len;
     }
 }
 

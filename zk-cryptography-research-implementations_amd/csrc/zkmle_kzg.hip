@@ -74,7 +74,9 @@ int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c,
     if (n >= ((size_t)1 << 31)) return ZK_E_ARG;            // index + sign are packed in 32 bits
     const unsigned nwin = (256 + c - 1) / c, nb = 1u << (c - 1);
     const size_t nbuckets = (size_t)nwin * nb;
-    size_t chunk_len = (n + 127) / 128;
+    // one (chunk, window) workgroup per CU-slot: long chunks make each workgroup write long runs per bucket
+    // (r1: 128 chunks -> scatter 6.4 ms at 2^24; the LDS cursors hold a whole window either way)
+    size_t chunk_len = (n + 15) / 16;
     if (chunk_len < 4096) chunk_len = 4096;
     const unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
     // one lane per bucket SEGMENT: cap the serial chain so that ~2^20 lanes exist whatever the window
@@ -98,8 +100,20 @@ int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c,
     ZK_HIP(hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     msm_hist_kernel<<<nwin * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len, (uint32_t *)hist.p);
     msm_chunk_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock>>>((uint32_t *)hist.p, nwin, nchunks, nb, (uint32_t *)totals.p);
-    msm_bucket_scan_kernel<<<1, kSortBlock>>>((const uint32_t *)totals.p, nbuckets, seg_len, (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
-    ZK_HIP(hipGetLastError());
+    {
+        unsigned ntiles = (unsigned)((nbuckets + kScanTile - 1) / kScanTile);
+        DevBuf te, ts, tm;
+        ZK_TRY(te.alloc((size_t)ntiles * 8));
+        ZK_TRY(ts.alloc((size_t)ntiles * 4));
+        ZK_TRY(tm.alloc((size_t)ntiles * 4));
+        msm_scan_tiles_kernel<<<ntiles, kScanTile>>>((const uint32_t *)totals.p, nbuckets, seg_len, (uint64_t *)te.p, (uint32_t *)ts.p, (uint32_t *)tm.p);
+        msm_scan_tile_totals_kernel<<<1, 64>>>((uint64_t *)te.p, (uint32_t *)ts.p, (const uint32_t *)tm.p, ntiles, nbuckets,
+                                              (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
+        msm_scan_apply_kernel<<<ntiles, kScanTile>>>((const uint32_t *)totals.p, nbuckets, seg_len, (const uint64_t *)te.p, (const uint32_t *)ts.p,
+                                                     (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipDeviceSynchronize());
+    }
     uint64_t entries = 0;
     uint32_t tail[2] = {0, 0};                              // {segments, largest per-bucket segment count}
     ZK_HIP(hipMemcpy(&entries, (uint64_t *)starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
