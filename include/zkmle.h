@@ -158,6 +158,11 @@ int zk_sumpoly_fold_round_evals(const zk_table *const *in, zk_table *const *out,
 int zk_sumcheck_gkr_prove(const zk_table *const *tables, size_t nprod, size_t nfac,
                           const uint64_t *claimed_sum, zk_transcript *t, uint64_t *round_coeffs,
                           uint64_t *challenges);
+/* the rounds of `prove` without the leading claimed-sum append (:37-60), for provers that run one
+ * sumcheck in several phases on one transcript (the sparse GKR prover).  final_values (may be NULL):
+ * the nprod*nfac one-entry tables left after the last fold. */
+int zk_sumcheck_gkr_rounds(const zk_table *const *tables, size_t nprod, size_t nfac, zk_transcript *t,
+                           uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values);
 /* verify :69-105 (host only: O(rounds) field operations) */
 int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_t *round_coeffs,
                            size_t nrounds, size_t ncoef, zk_transcript *t, uint64_t *challenges,
@@ -244,6 +249,32 @@ int zk_gkr_prove_succinct(const zk_gate *gates, const size_t *gate_counts, size_
                           uint64_t *wb_evals, uint64_t *wc_evals, uint64_t *commitment12,
                           uint64_t *rb_evaluation, uint64_t *rb_proofs, uint64_t *rc_evaluation,
                           uint64_t *rc_proofs);
+
+/* ---- sparse (linear-time) GKR prover: the generalisation BASELINE config 4 needs -------------------------
+ * The reference materialises dense wiring predicates add_i / mul_i of 2^(3i+2) entries and a dense f(b,c) of
+ * 2^(2i+2) entries (arithmetic_circuit.rs:126-163, utils.rs:8-21) and ties a layer's width to its index
+ * (:166-178).  Here a layer is a gate LIST (out, left, right, op) with its own widths: layer l has
+ * 2^out_bits[l] outputs and reads the 2^out_bits[l+1] wires of the next layer (the inputs for the last one).
+ * Each layer's 2k-round sumcheck is run in two phases (b then c) on tables built from the gate list in
+ * O(#gates + 2^k):   phase 1  f = W(b) H1(b) + H0(b),   phase 2  f = A(c)(u + W(c)) + M(c) u W(c).
+ * The round polynomials are the SAME polynomials as the dense definition's, so on circuits of the
+ * reference's shape the proof is bit-identical to zk_gkr_prove / gkr_protocol::prove (tests/test_gpu_gkr_sparse.py).
+ * With out_bits[0] = k0 > 1 the output claim uses k0 successive challenges (the reference has k0 = 1).
+ * Proof layout as zk_gkr_prove with rounds(l) = 2 * in_bits(l). */
+int zk_gkr_sparse_prove(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers,
+                        const uint32_t *out_bits, const uint64_t *inputs, size_t ninputs,
+                        uint64_t *circuit_output, uint64_t *claimed_sum, uint64_t *layer_claims,
+                        uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals,
+                        uint64_t *output_challenges /* out_bits[0] elements */, float *ms_layers /* nlayers, may be NULL */);
+/* independent evaluation of the wiring predicates at a point (the verifier's O(#gates) work):
+ * add_r = sum_{add gates} w_g eq(rb, left_g) eq(rc, right_g), same for mul, with
+ * w_g = alpha eq(pa, out_g) + beta eq(pb, out_g)  (layer 0: alpha = 1, beta = 0, pa = output challenges). */
+int zk_gkr_sparse_wiring_eval(int field, const zk_gate *layer_gates, size_t ngates, uint32_t out_bits, uint32_t in_bits,
+                              const uint64_t *alpha, const uint64_t *pa, const uint64_t *beta, const uint64_t *pb,
+                              const uint64_t *rb, const uint64_t *rc, uint64_t *add_r, uint64_t *mul_r);
+/* layer-by-layer evaluation of a sparse circuit on the GPU; evals = layer 0 .. inputs concatenated */
+int zk_sparse_circuit_evaluate(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers,
+                               const uint32_t *out_bits, const uint64_t *inputs, size_t ninputs, uint64_t *evals);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,104 @@
+"""GPU: the sparse (linear-time) GKR prover.  On circuits of the reference's shape its proof must be
+bit-identical to the dense definition (oracle = restatement of gkr/src/gkr_protocol.rs); on wide circuits
+(which the reference cannot express) it is checked by the verifier equations with an independently
+evaluated wiring predicate."""
+import random
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as G
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+OPS = {"add": 0, "mul": 1}
+
+
+@pytest.fixture(scope="module")
+def zk():
+    zk = G.import_package()
+    from zkmle_amd import _lib
+    _lib.check(zk.lib().zk_init(0))
+    return zk
+
+
+def rows_of(spec):
+    return [np.array([[g[0], g[1], g[2], OPS[g[3]] if isinstance(g[3], str) else g[3]] for g in layer], np.uint64) for layer in spec]
+
+
+def ref_shape_bits(nlayers):
+    return [1] + list(range(1, nlayers))          # layer 0: one a-bit (arithmetic_circuit.rs:167-169), layer i: i bits
+
+
+def check_dense_parity(zk, f, spec, inputs_ints):
+    x = zk.from_ints(f, inputs_ints)
+    ob = ref_shape_bits(len(spec))
+    proof = zk.gkr.sparse_prove(f, rows_of(spec), ob, x)
+    want = O.gkr_prove(f, [[(g[0], g[1], g[2], OPS[g[3]] if isinstance(g[3], str) else g[3]) for g in layer] for layer in spec], x)
+    out = want["circuit_output"]
+    assert np.array_equal(proof.circuit_output[: len(out)], out) and not proof.circuit_output[len(out):].any()
+    assert np.array_equal(proof.claimed_sum, want["claimed_sum"])
+    assert np.array_equal(proof.layer_claims, want["layer_claims"])
+    assert np.array_equal(proof.coeffs, want["coeffs"])
+    assert np.array_equal(proof.challenges, want["challenges"])
+    assert np.array_equal(proof.wb_evals, want["wb_evals"]) and np.array_equal(proof.wc_evals, want["wc_evals"])
+    assert zk.gkr.sparse_verify(f, rows_of(spec), ob, proof, x) is True
+    return proof
+
+
+def test_reference_circuits_bit_identical_to_dense(zk, ref_kats, derived_kats):
+    for k in ref_kats["gkr_roundtrip"]:                       # gkr_protocol.rs:246-299
+        check_dense_parity(zk, 2, k["layers"], k["inputs"])
+    for d in derived_kats["gkr_prove"]:
+        p = check_dense_parity(zk, 2, d["layers"], d["inputs"])
+        assert zk.to_ints(2, p.claimed_sum) == [int(d["claimed_sum"], 16)]
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5])
+def test_random_reference_shaped_circuits(zk, depth):
+    rng = random.Random(40 + depth)
+    f = 0
+    p = O.modulus(f)
+    spec = []
+    for i in range(depth):
+        n_out, n_in = (1 << i), (1 << (i + 1))
+        seen, layer = set(), []
+        for o in range(n_out):
+            for _ in range(rng.choice([1, 1, 2])):           # some outputs are sums of two gates (+=, :96)
+                g = (rng.randrange(n_in), rng.randrange(n_in), o, rng.choice(["add", "mul"]))
+                if g not in seen:
+                    seen.add(g)
+                    layer.append(list(g))
+        spec.append(layer)
+    check_dense_parity(zk, f, spec, [rng.randrange(p) for _ in range(1 << depth)])
+
+
+@pytest.mark.parametrize("bits", [(3, 5, 4, 6), (10, 10, 10, 10), (1, 12, 3, 7)])
+def test_wide_circuits_verify(zk, bits):
+    """layers of arbitrary widths and random wiring (not expressible in the reference): prove, then verify"""
+    rng = np.random.default_rng(sum(bits))
+    f = 0
+    *out_bits, in_bits_last = bits
+    widths = list(out_bits) + [in_bits_last]
+    rows = []
+    for l in range(len(out_bits)):
+        n_out, n_in = 1 << widths[l], 1 << widths[l + 1]
+        g = np.zeros((n_out, 4), np.uint64)
+        g[:, 0] = rng.integers(0, n_in, n_out)
+        g[:, 1] = rng.integers(0, n_in, n_out)
+        g[:, 2] = np.arange(n_out)
+        g[:, 3] = rng.integers(0, 2, n_out)
+        rows.append(g)
+    x = zk.MultilinearPolynomial.random(f, 1 << in_bits_last, 5).evaluated_values
+    proof = zk.gkr.sparse_prove(f, rows, out_bits, x)
+    assert zk.gkr.sparse_verify(f, rows, out_bits, proof, x) is True
+    # the circuit evaluation agrees with the reference's evaluator (oracle) on the same gate lists
+    evs = O.circuit_evaluate(f, [[tuple(int(v) for v in r) for r in layer] for layer in rows], x)
+    assert np.array_equal(proof.circuit_output[: len(evs[0])], evs[0])
+    bad = x.copy()
+    bad[3, 0] ^= np.uint64(1)
+    assert zk.gkr.sparse_verify(f, rows, out_bits, proof, bad) is False
+    tampered = zk.gkr.SparseProof(**{**proof.__dict__, "wb_evals": proof.wb_evals.copy()})
+    if len(tampered.wb_evals):
+        tampered.wb_evals[0, 0] ^= np.uint64(1)
+        assert zk.gkr.sparse_verify(f, rows, out_bits, tampered, x) is False

@@ -1,0 +1,413 @@
+// zkmle_gkr_sparse.hip -- C ABI: linear-time (sparse-wiring) GKR prover, the generalisation that BASELINE
+// config 4 (depth-3 circuit, 2^22 gates per layer) needs.  See include/zkmle.h for the contract.
+//
+// Per layer the reference (gkr/src/gkr_protocol.rs:57-133) builds dense add_i / mul_i tables of 2^(3i+2)
+// entries, folds them by ra (or alpha/beta-combines two fold chains, utils.rs:23-68), forms the dense
+// f(b,c) = add(b,c)(W(b)+W(c)) + mul(b,c) W(b) W(c) over 2^(2i+2) entries and runs a 2(i+1)-round sumcheck.
+// With w_g = eq(ra, out_g) (or alpha eq(rb', out_g) + beta eq(rc', out_g)) the same round polynomials are:
+//   rounds over b:  sum_c f(b,c) = W(b) H1(b) + H0(b),
+//                   H1(b) = sum_{g: left_g = b} w_g ([add] + [mul] W(right_g)),   H0(b) = sum_{g add: left_g = b} w_g W(right_g)
+//   rounds over c (b fixed to rb*, u = W(rb*)):
+//                   f(rb*, c) = A(c)(u + W(c)) + M(c) u W(c),   A / M(c) = sum_{g add / mul: right_g = c} w_g eq(rb*, left_g)
+// Both phases are the product's generic sum-of-products sumcheck on 4 tables of 2^k entries
+// ([W,H1],[H0,1] then [A,u+W],[M,uW]), so all table work reuses the fused HIP round kernels.
+#include <string.h>
+
+#include <memory>
+#include <vector>
+
+#include "context.h"
+#include "sumcheck_kernels.cuh"
+#include "transcript.h"
+
+using namespace zk;
+
+namespace {
+
+struct TableDeleter { void operator()(zk_table *t) const { zk_table_free(t); } };
+using TablePtr = std::unique_ptr<zk_table, TableDeleter>;
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { ZK_HIP(hipMalloc(&p, bytes ? bytes : 16)); return ZK_OK; }
+    int upload(const void *src, size_t bytes) { ZK_TRY(alloc(bytes)); if (bytes) ZK_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice)); return ZK_OK; }
+};
+template <class F> Fe<F> load_el(const uint64_t *src) { Fe<F> e; memcpy(e.l, src, 4 * F::N); return e; }
+template <class F> void store_el(uint64_t *dst, const Fe<F> &e) { memcpy(dst, e.l, 4 * F::N); }
+
+int alloc_table(int field, size_t len, TablePtr &out) {
+    zk_table *t = nullptr;
+    ZK_TRY(zk_table_alloc(field, len, &t));
+    out.reset(t);
+    return ZK_OK;
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------
+// eq table: out[2j] = in[j] (1 - tau), out[2j+1] = in[j] tau  (variable 0 = MSB first)
+template <class F> __global__ void eq_expand_kernel_t(const void *__restrict__ in, void *__restrict__ out, size_t len, Fe<F> tau) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    Fe<F> omt = fe_sub<F>(fe_one<F>(), tau);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride) {
+        Fe<F> v = fe_load<F>(in, j);
+        fe_store<F>(out, 2 * j, fe_mul<F>(v, omt));
+        fe_store<F>(out, 2 * j + 1, fe_mul<F>(v, tau));
+    }
+}
+template <class F> __global__ void fill_one_kernel(void *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store<F>(out, i, fe_one<F>());
+}
+struct GateArrays {
+    const uint32_t *out, *left, *right, *op;      // SoA on the device
+};
+// w[g] = alpha eqA[out_g] + beta eqB[out_g]   (eqB may be null: layer 0)
+template <class F> __global__ void gate_weights_kernel(GateArrays g, size_t n, const void *eqA, const void *eqB, Fe<F> alpha, Fe<F> beta,
+                                                       void *__restrict__ w) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> v = fe_load<F>(eqA, g.out[i]);
+    if (eqB) v = fe_add<F>(fe_mul<F>(alpha, v), fe_mul<F>(beta, fe_load<F>(eqB, g.out[i])));
+    fe_store<F>(w, i, v);
+}
+// one lane per left index b (gates grouped by left index: order / start)
+template <class F> __global__ void phase1_tables_kernel(GateArrays g, const uint32_t *__restrict__ order, const uint32_t *__restrict__ start,
+                                                        size_t nb, const void *__restrict__ w, const void *__restrict__ W,
+                                                        void *__restrict__ H1, void *__restrict__ H0) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    Fe<F> h1 = fe_zero<F>(), h0 = fe_zero<F>();
+    for (uint32_t e = start[b]; e < start[b + 1]; e++) {
+        uint32_t i = order[e];
+        Fe<F> wg = fe_load<F>(w, i);
+        Fe<F> t = fe_mul<F>(wg, fe_load<F>(W, g.right[i]));
+        if (g.op[i] == 0) { h1 = fe_add<F>(h1, wg); h0 = fe_add<F>(h0, t); }     // add gate
+        else h1 = fe_add<F>(h1, t);                                               // mul gate
+    }
+    fe_store<F>(H1, b, h1);
+    fe_store<F>(H0, b, h0);
+}
+// one lane per right index c (gates grouped by right index)
+template <class F> __global__ void phase2_tables_kernel(GateArrays g, const uint32_t *__restrict__ order, const uint32_t *__restrict__ start,
+                                                        size_t nc, const void *__restrict__ w, const void *__restrict__ eqL,
+                                                        void *__restrict__ A, void *__restrict__ M) {
+    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    Fe<F> a = fe_zero<F>(), m = fe_zero<F>();
+    for (uint32_t e = start[c]; e < start[c + 1]; e++) {
+        uint32_t i = order[e];
+        Fe<F> t = fe_mul<F>(fe_load<F>(w, i), fe_load<F>(eqL, g.left[i]));
+        if (g.op[i] == 0) a = fe_add<F>(a, t); else m = fe_add<F>(m, t);
+    }
+    fe_store<F>(A, c, a);
+    fe_store<F>(M, c, m);
+}
+template <class F> __global__ void uw_tables_kernel(const void *__restrict__ W, size_t n, Fe<F> u, void *__restrict__ upw, void *__restrict__ utw) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> x = fe_load<F>(W, i);
+    fe_store<F>(upw, i, fe_add<F>(u, x));
+    fe_store<F>(utw, i, fe_mul<F>(u, x));
+}
+// out[o] = sum over the gates with output o of op(in[left], in[right])   (arithmetic_circuit.rs:86-97, += semantics)
+template <class F> __global__ void circuit_layer_kernel(GateArrays g, const uint32_t *__restrict__ order, const uint32_t *__restrict__ start,
+                                                        size_t nout, const void *__restrict__ in, void *__restrict__ out) {
+    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nout) return;
+    Fe<F> acc = fe_zero<F>();
+    for (uint32_t e = start[o]; e < start[o + 1]; e++) {
+        uint32_t i = order[e];
+        Fe<F> a = fe_load<F>(in, g.left[i]), b = fe_load<F>(in, g.right[i]);
+        acc = fe_add<F>(acc, g.op[i] == 0 ? fe_add<F>(a, b) : fe_mul<F>(a, b));
+    }
+    fe_store<F>(out, o, acc);
+}
+// partial sums over gates of w_g eqL[left] eqR[right] split by gate type (verifier-side check)
+template <class F> __global__ void wiring_eval_kernel(GateArrays g, size_t n, const void *w, const void *eqL, const void *eqR, void *partials) {
+    __shared__ Fe<F> sh[kBlock / 64];
+    Fe<F> a = fe_zero<F>(), m = fe_zero<F>();
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Fe<F> t = fe_mul<F>(fe_mul<F>(fe_load<F>(w, i), fe_load<F>(eqL, g.left[i])), fe_load<F>(eqR, g.right[i]));
+        if (g.op[i] == 0) a = fe_add<F>(a, t); else m = fe_add<F>(m, t);
+    }
+    Fe<F> ta = block_reduce_add<F>(a, sh);
+    Fe<F> tm = block_reduce_add<F>(m, sh);
+    if (threadIdx.x == 0) {
+        fe_store<F>(partials, blockIdx.x, ta);
+        fe_store<F>(partials, (size_t)gridDim.x + blockIdx.x, tm);
+    }
+}
+
+// ---- host-side circuit structure ------------------------------------------------------------------------------
+struct LayerDev {
+    size_t ngates = 0;
+    uint32_t out_bits = 0, in_bits = 0;
+    DevBuf out, left, right, op;                       // u32[ngates]
+    DevBuf ord_left, st_left, ord_right, st_right, ord_out, st_out;
+    GateArrays arrays() const { return GateArrays{(const uint32_t *)out.p, (const uint32_t *)left.p, (const uint32_t *)right.p, (const uint32_t *)op.p}; }
+};
+// counting sort of gate ids by key: order[], start[nbins + 1]
+void group_by(const std::vector<uint32_t> &key, size_t nbins, std::vector<uint32_t> &order, std::vector<uint32_t> &start) {
+    start.assign(nbins + 1, 0);
+    for (uint32_t k : key) start[k + 1]++;
+    for (size_t b = 0; b < nbins; b++) start[b + 1] += start[b];
+    order.resize(key.size());
+    std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < key.size(); i++) order[cur[key[i]]++] = (uint32_t)i;
+}
+int upload_layer(const zk_gate *g, size_t n, uint32_t out_bits, uint32_t in_bits, LayerDev &L) {
+    std::vector<uint32_t> out(n), left(n), right(n), op(n);
+    for (size_t i = 0; i < n; i++) {
+        if ((g[i].out >> out_bits) || (g[i].left >> in_bits) || (g[i].right >> in_bits) || g[i].op > 1) return ZK_E_RANGE;
+        out[i] = (uint32_t)g[i].out; left[i] = (uint32_t)g[i].left; right[i] = (uint32_t)g[i].right; op[i] = (uint32_t)g[i].op;
+    }
+    L.ngates = n; L.out_bits = out_bits; L.in_bits = in_bits;
+    ZK_TRY(L.out.upload(out.data(), n * 4));
+    ZK_TRY(L.left.upload(left.data(), n * 4));
+    ZK_TRY(L.right.upload(right.data(), n * 4));
+    ZK_TRY(L.op.upload(op.data(), n * 4));
+    std::vector<uint32_t> order, start;
+    group_by(left, (size_t)1 << in_bits, order, start);
+    ZK_TRY(L.ord_left.upload(order.data(), n * 4));
+    ZK_TRY(L.st_left.upload(start.data(), start.size() * 4));
+    group_by(right, (size_t)1 << in_bits, order, start);
+    ZK_TRY(L.ord_right.upload(order.data(), n * 4));
+    ZK_TRY(L.st_right.upload(start.data(), start.size() * 4));
+    group_by(out, (size_t)1 << out_bits, order, start);
+    ZK_TRY(L.ord_out.upload(order.data(), n * 4));
+    ZK_TRY(L.st_out.upload(start.data(), start.size() * 4));
+    return ZK_OK;
+}
+
+inline unsigned blocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// eq(point, .) over 2^nbits entries, built level by level in HBM
+template <class F> int eq_table(const uint64_t *point, uint32_t nbits, TablePtr &out) {
+    size_t n = (size_t)1 << nbits;
+    TablePtr a, b;
+    ZK_TRY(alloc_table(F::ID, n, a));
+    ZK_TRY(alloc_table(F::ID, n, b));
+    Fe<F> one = fe_one<F>();
+    ZK_HIP(hipMemcpy(a->dptr, one.l, 4 * F::N, hipMemcpyHostToDevice));
+    zk_table *cur = a.get(), *nxt = b.get();
+    size_t len = 1;
+    for (uint32_t i = 0; i < nbits; i++) {
+        eq_expand_kernel_t<F><<<grid_for(len), kBlock>>>(cur->dptr, nxt->dptr, len, load_el<F>(point + (size_t)i * (F::N / 2)));
+        ZK_HIP(hipGetLastError());
+        zk_table *t = cur; cur = nxt; nxt = t;
+        len *= 2;
+    }
+    if (cur == a.get()) out = std::move(a); else out = std::move(b);
+    out->len = n;
+    return ZK_OK;
+}
+
+template <class F> int evaluate_layers(std::vector<LayerDev> &layers, const uint64_t *inputs, size_t ninputs, std::vector<TablePtr> &W) {
+    size_t nl = layers.size();
+    W.resize(nl + 1);
+    zk_table *t = nullptr;
+    ZK_TRY(zk_table_upload(F::ID, inputs, ninputs, &t));
+    W[nl].reset(t);
+    for (size_t l = nl; l-- > 0;) {
+        size_t nout = (size_t)1 << layers[l].out_bits;
+        ZK_TRY(alloc_table(F::ID, nout, W[l]));
+        circuit_layer_kernel<F><<<blocks(nout), kBlock>>>(layers[l].arrays(), (const uint32_t *)layers[l].ord_out.p, (const uint32_t *)layers[l].st_out.p,
+                                                           nout, W[l + 1]->dptr, W[l]->dptr);
+        ZK_HIP(hipGetLastError());
+    }
+    ZK_HIP(hipDeviceSynchronize());
+    return ZK_OK;
+}
+
+int build_layers(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint32_t *out_bits, size_t ninputs,
+                 std::vector<LayerDev> &layers) {
+    if (!is_pow2(ninputs)) return ZK_E_NOT_POW2;
+    layers.resize(nlayers);
+    size_t off = 0;
+    for (size_t l = 0; l < nlayers; l++) {
+        uint32_t in_bits = l + 1 < nlayers ? out_bits[l + 1] : ilog2(ninputs);
+        if (out_bits[l] > 30 || in_bits > 30 || in_bits == 0) return ZK_E_ARG;
+        ZK_TRY(upload_layer(gates + off, gate_counts[l], out_bits[l], in_bits, layers[l]));
+        off += gate_counts[l];
+    }
+    return ZK_OK;
+}
+
+template <class F> int sparse_prove(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint32_t *out_bits,
+                                    const uint64_t *inputs, size_t ninputs, uint64_t *circuit_output, uint64_t *claimed_sum,
+                                    uint64_t *layer_claims, uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals,
+                                    uint64_t *output_challenges, float *ms_layers) {
+    const size_t L64 = F::N / 2, esz = 4 * F::N;
+    std::vector<LayerDev> layers;
+    ZK_TRY(build_layers(gates, gate_counts, nlayers, out_bits, ninputs, layers));
+    std::vector<TablePtr> W;
+    ZK_TRY((evaluate_layers<F>(layers, inputs, ninputs, W)));                        // Circuit::evaluate (arithmetic_circuit.rs:65-109)
+    size_t nout = (size_t)1 << out_bits[0];
+    ZK_TRY(zk_table_download(W[0].get(), circuit_output));
+    zk_transcript tr;
+    {   // transcript.append(w0 bytes) gkr_protocol.rs:49 (an output layer of one wire is one gate plus a zero pad, :43-47)
+        std::vector<uint8_t> bytes(nout * esz);
+        ZK_TRY(zk_mle_to_bytes(W[0].get(), bytes.data()));
+        tr.t.append(bytes.data(), bytes.size());
+    }
+    std::vector<uint64_t> ra((size_t)out_bits[0] * L64);
+    for (uint32_t i = 0; i < out_bits[0]; i++) store_el<F>(ra.data() + i * L64, tr.t.random_challenge_as_field_element<F>());   // :50
+    memcpy(output_challenges, ra.data(), ra.size() * 8);
+    uint64_t claim[6], alpha[6] = {0}, beta[6] = {0};
+    ZK_TRY(zk_mle_evaluate(W[0].get(), ra.data(), out_bits[0], claim));              // :51
+    std::vector<uint64_t> rb, rc;
+    size_t coff = 0, choff = 0;
+    for (size_t l = 0; l < nlayers; l++) {                                           // :57
+        hipEvent_t e0, e1;
+        ZK_HIP(hipEventCreate(&e0));
+        ZK_HIP(hipEventCreate(&e1));
+        ZK_HIP(hipEventRecord(e0, nullptr));
+        LayerDev &Ly = layers[l];
+        const uint32_t k = Ly.in_bits;
+        const size_t nk = (size_t)1 << k, ng = Ly.ngates;
+        const zk_table *Wn = W[l + 1].get();
+        // gate weights
+        TablePtr eqA, eqB;
+        DevBuf w;
+        ZK_TRY(w.alloc(ng * esz));
+        if (l == 0) {
+            ZK_TRY((eq_table<F>(ra.data(), Ly.out_bits, eqA)));
+            gate_weights_kernel<F><<<blocks(ng), kBlock>>>(Ly.arrays(), ng, eqA->dptr, nullptr, fe_zero<F>(), fe_zero<F>(), w.p);
+        } else {
+            ZK_TRY((eq_table<F>(rb.data(), Ly.out_bits, eqA)));
+            ZK_TRY((eq_table<F>(rc.data(), Ly.out_bits, eqB)));
+            gate_weights_kernel<F><<<blocks(ng), kBlock>>>(Ly.arrays(), ng, eqA->dptr, eqB->dptr, load_el<F>(alpha), load_el<F>(beta), w.p);
+        }
+        ZK_HIP(hipGetLastError());
+        // phase 1: W H1 + H0 * 1
+        TablePtr H1, H0, ones;
+        ZK_TRY(alloc_table(F::ID, nk, H1));
+        ZK_TRY(alloc_table(F::ID, nk, H0));
+        ZK_TRY(alloc_table(F::ID, nk, ones));
+        phase1_tables_kernel<F><<<blocks(nk), kBlock>>>(Ly.arrays(), (const uint32_t *)Ly.ord_left.p, (const uint32_t *)Ly.st_left.p, nk, w.p,
+                                                         Wn->dptr, H1->dptr, H0->dptr);
+        fill_one_kernel<F><<<blocks(nk), kBlock>>>(ones->dptr, nk);
+        ZK_HIP(hipGetLastError());
+        memcpy(layer_claims + l * L64, claim, L64 * 8);
+        tr.t.append_be<F>(load_el<F>(claim));                                        // sumcheck_gkr_protocol.rs:35
+        uint64_t *lco = coeffs + coff * L64, *lch = challenges + choff * L64;
+        uint64_t fin[4 * 6];
+        const zk_table *t1[4] = {Wn, H1.get(), H0.get(), ones.get()};
+        ZK_TRY(zk_sumcheck_gkr_rounds(t1, 2, 2, &tr, lco, lch, fin));                // rounds over b
+        uint64_t u[6];
+        memcpy(u, fin, L64 * 8);                                                     // W(rb*)
+        // phase 2: A (u + W) + M (u W)
+        TablePtr eqL, A, M, upw, utw;
+        ZK_TRY((eq_table<F>(lch, k, eqL)));
+        ZK_TRY(alloc_table(F::ID, nk, A));
+        ZK_TRY(alloc_table(F::ID, nk, M));
+        ZK_TRY(alloc_table(F::ID, nk, upw));
+        ZK_TRY(alloc_table(F::ID, nk, utw));
+        phase2_tables_kernel<F><<<blocks(nk), kBlock>>>(Ly.arrays(), (const uint32_t *)Ly.ord_right.p, (const uint32_t *)Ly.st_right.p, nk, w.p,
+                                                         eqL->dptr, A->dptr, M->dptr);
+        uw_tables_kernel<F><<<blocks(nk), kBlock>>>(Wn->dptr, nk, load_el<F>(u), upw->dptr, utw->dptr);
+        ZK_HIP(hipGetLastError());
+        const zk_table *t2[4] = {A.get(), upw.get(), M.get(), utw.get()};
+        ZK_TRY(zk_sumcheck_gkr_rounds(t2, 2, 2, &tr, lco + (size_t)k * 3 * L64, lch + (size_t)k * L64, fin));   // rounds over c
+        if (l + 1 < nlayers) {                                                       // gkr_protocol.rs:109-133
+            uint64_t wce[6];
+            Fe<F> wb = load_el<F>(u);
+            Fe<F> wc = fe_sub<F>(load_el<F>(fin + L64), wb);                         // (u + W)(rc*) - u = W(rc*)
+            store_el<F>(wce, wc);
+            memcpy(wb_evals + l * L64, u, L64 * 8);
+            memcpy(wc_evals + l * L64, wce, L64 * 8);
+            rb.assign(lch, lch + (size_t)k * L64);
+            rc.assign(lch + (size_t)k * L64, lch + (size_t)2 * k * L64);
+            tr.t.append_be<F>(wb);                                                   // :125
+            Fe<F> a = tr.t.random_challenge_as_field_element<F>();
+            tr.t.append_be<F>(wc);                                                   // :128
+            Fe<F> b = tr.t.random_challenge_as_field_element<F>();
+            store_el<F>(alpha, a);
+            store_el<F>(beta, b);
+            store_el<F>(claim, fe_add<F>(fe_mul<F>(a, wb), fe_mul<F>(b, wc)));       // :132
+        }
+        coff += (size_t)2 * k * 3;
+        choff += (size_t)2 * k;
+        ZK_HIP(hipEventRecord(e1, nullptr));
+        ZK_HIP(hipEventSynchronize(e1));
+        if (ms_layers) (void)hipEventElapsedTime(&ms_layers[l], e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    memcpy(claimed_sum, claim, L64 * 8);
+    return ZK_OK;
+}
+
+template <class F> int wiring_eval(const zk_gate *g, size_t ngates, uint32_t out_bits, uint32_t in_bits, const uint64_t *alpha, const uint64_t *pa,
+                                   const uint64_t *beta, const uint64_t *pb, const uint64_t *rb, const uint64_t *rc, uint64_t *add_r, uint64_t *mul_r) {
+    const size_t esz = 4 * F::N;
+    LayerDev L;
+    ZK_TRY(upload_layer(g, ngates, out_bits, in_bits, L));
+    TablePtr eqA, eqB, eqL, eqR;
+    ZK_TRY((eq_table<F>(pa, out_bits, eqA)));
+    if (pb) ZK_TRY((eq_table<F>(pb, out_bits, eqB)));
+    ZK_TRY((eq_table<F>(rb, in_bits, eqL)));
+    ZK_TRY((eq_table<F>(rc, in_bits, eqR)));
+    DevBuf w;
+    ZK_TRY(w.alloc(ngates * esz));
+    gate_weights_kernel<F><<<blocks(ngates), kBlock>>>(L.arrays(), ngates, eqA->dptr, pb ? eqB->dptr : nullptr,
+                                                        pb ? load_el<F>(alpha) : fe_zero<F>(), pb ? load_el<F>(beta) : fe_zero<F>(), w.p);
+    int grid = reduce_grid_for(ngates);
+    void *part;
+    ZK_TRY(scratch(esz * ((size_t)grid * 2 + 2), &part));
+    void *res = (char *)part + esz * (size_t)grid * 2;
+    wiring_eval_kernel<F><<<grid, kBlock>>>(L.arrays(), ngates, w.p, eqL->dptr, eqR->dptr, part);
+    finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, 2, res);
+    ZK_HIP(hipGetLastError());
+    uint64_t both[12];
+    ZK_HIP(hipMemcpy(both, res, esz * 2, hipMemcpyDeviceToHost));
+    memcpy(add_r, both, esz);
+    memcpy(mul_r, both + F::N / 2, esz);
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zk_gkr_sparse_prove(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint32_t *out_bits,
+                        const uint64_t *inputs, size_t ninputs, uint64_t *circuit_output, uint64_t *claimed_sum, uint64_t *layer_claims,
+                        uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals, uint64_t *output_challenges,
+                        float *ms_layers) {
+    if (!gates || !gate_counts || !out_bits || !inputs || !circuit_output || !claimed_sum || !layer_claims || !coeffs || !challenges ||
+        !output_challenges || nlayers == 0)
+        return ZK_E_ARG;
+    if (nlayers > 1 && (!wb_evals || !wc_evals)) return ZK_E_ARG;
+    if (out_bits[0] == 0) return ZK_E_ARG;      // a single output wire is padded to two by the caller (gkr_protocol.rs:43-47)
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(field, return sparse_prove<F>(gates, gate_counts, nlayers, out_bits, inputs, ninputs, circuit_output, claimed_sum,
+                                                    layer_claims, coeffs, challenges, wb_evals, wc_evals, output_challenges, ms_layers));
+    return ZK_OK;
+}
+int zk_gkr_sparse_wiring_eval(int field, const zk_gate *layer_gates, size_t ngates, uint32_t out_bits, uint32_t in_bits, const uint64_t *alpha,
+                              const uint64_t *pa, const uint64_t *beta, const uint64_t *pb, const uint64_t *rb, const uint64_t *rc,
+                              uint64_t *add_r, uint64_t *mul_r) {
+    if (!layer_gates || !pa || !rb || !rc || !add_r || !mul_r || (pb && (!alpha || !beta))) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(field, return wiring_eval<F>(layer_gates, ngates, out_bits, in_bits, alpha, pa, beta, pb, rb, rc, add_r, mul_r));
+    return ZK_OK;
+}
+int zk_sparse_circuit_evaluate(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint32_t *out_bits,
+                               const uint64_t *inputs, size_t ninputs, uint64_t *evals) {
+    if (!gates || !gate_counts || !out_bits || !inputs || !evals) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    std::vector<LayerDev> layers;
+    ZK_TRY(build_layers(gates, gate_counts, nlayers, out_bits, ninputs, layers));
+    ZK_DISPATCH_FIELD(field, {
+        std::vector<TablePtr> W;
+        ZK_TRY((evaluate_layers<F>(layers, inputs, ninputs, W)));
+        size_t off = 0;
+        for (size_t l = 0; l <= nlayers; l++) {
+            ZK_TRY(zk_table_download(W[l].get(), evals + off * (F::N / 2)));
+            off += W[l]->len;
+        }
+    });
+    return ZK_OK;
+}
+
+}  // extern "C"

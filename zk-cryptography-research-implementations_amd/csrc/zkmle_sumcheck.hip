@@ -191,14 +191,17 @@ template <class F> int round_evals(const zk_table *const *tables, size_t nprod, 
 }
 
 // ---- GKR sumcheck prover: sumcheck_gkr_protocol.rs:24-67 --------------------------------------------------
-template <class F> int gkr_sumcheck_prove(const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *claimed_sum,
-                                          Transcript &tr, uint64_t *round_coeffs, uint64_t *challenges) {
+template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t nprod, size_t nfac, Transcript &tr,
+                                           uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values) {
     const size_t esz = 4 * F::N, L64 = F::N / 2;
     const size_t ntab = nprod * nfac, npts = nfac + 1;                 // degree() = polynomials.len() (:114, sum_polynomial.rs:88)
     size_t len = tables[0]->len;
     unsigned nvars = ilog2(len);                                       // :29
-    tr.append_be<F>(load_el<F>(claimed_sum));                          // :35
-    if (nvars == 0) return ZK_OK;
+    if (nvars == 0) {
+        if (final_values)
+            for (size_t k = 0; k < ntab; k++) ZK_HIP(hipMemcpy(final_values + k * L64, tables[k]->dptr, esz, hipMemcpyDeviceToHost));
+        return ZK_OK;
+    }
     DevBuf bufA, bufB;
     ZK_TRY(bufA.alloc(ntab * (len / 2) * esz));
     ZK_TRY(bufB.alloc(ntab * (len / 4) * esz));
@@ -249,7 +252,15 @@ template <class F> int gkr_sumcheck_prove(const zk_table *const *tables, size_t 
         cl = ol;
     }
     ZK_HIP(hipDeviceSynchronize());
+    if (final_values)
+        for (size_t k = 0; k < ntab; k++) ZK_HIP(hipMemcpy(final_values + k * L64, tabs.in[k], esz, hipMemcpyDeviceToHost));
     return ZK_OK;
+}
+
+template <class F> int gkr_sumcheck_prove(const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *claimed_sum,
+                                          Transcript &tr, uint64_t *round_coeffs, uint64_t *challenges) {
+    tr.append_be<F>(load_el<F>(claimed_sum));                          // :35
+    return gkr_sumcheck_rounds<F>(tables, nprod, nfac, tr, round_coeffs, challenges, nullptr);
 }
 
 template <class F> int gkr_sumcheck_verify(const uint64_t *claimed_sum, const uint64_t *round_coeffs, size_t nrounds, size_t ncoef,
@@ -414,6 +425,15 @@ int zk_sumcheck_gkr_prove(const zk_table *const *tables, size_t nprod, size_t nf
     if ((nprod < 2 || nfac < 2) && tables[0]->len > 1) return ZK_E_NEED_TWO;   // first round's generate_round_univariate panics
     ZK_TRY(require_device());
     ZK_DISPATCH_FIELD(tables[0]->field, return gkr_sumcheck_prove<F>(tables, nprod, nfac, claimed_sum, t->t, round_coeffs, challenges));
+    return ZK_OK;
+}
+int zk_sumcheck_gkr_rounds(const zk_table *const *tables, size_t nprod, size_t nfac, zk_transcript *t, uint64_t *round_coeffs,
+                           uint64_t *challenges, uint64_t *final_values) {
+    ZK_TRY(check_sumpoly(tables, nprod, nfac));
+    if (!t || !round_coeffs || !challenges) return ZK_E_ARG;
+    if ((nprod < 2 || nfac < 2) && tables[0]->len > 1) return ZK_E_NEED_TWO;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(tables[0]->field, return gkr_sumcheck_rounds<F>(tables, nprod, nfac, t->t, round_coeffs, challenges, final_values));
     return ZK_OK;
 }
 int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_t *round_coeffs, size_t nrounds, size_t ncoef,

@@ -219,3 +219,121 @@ def prove_succinct(circuit, inputs, trusted_setup):
         off += r
     base = Proof(out[: olen.value], cs, proofs, wb[: nl - 1], wc[: nl - 1], _flat=(claims, co, ch))
     return SuccinctProof(base, commit, MultilinearKZGProof(rb_ev, rb_pr), MultilinearKZGProof(rc_ev, rc_pr))
+
+
+# ---- sparse (linear-time) GKR: layers are gate lists with their own widths (include/zkmle.h) -----------------
+def _decl_sparse():
+    lib = _decl()
+    if getattr(lib, "_sparse_declared", False):
+        return lib
+    u64p, sz, gp, szp = L.u64p, L.sz, C.POINTER(_Gate), C.POINTER(C.c_size_t)
+    u32p, fp = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+    lib.zk_gkr_sparse_prove.argtypes = [C.c_int, gp, szp, sz, u32p, u64p, sz] + [u64p] * 8 + [fp]
+    lib.zk_gkr_sparse_prove.restype = C.c_int
+    lib.zk_gkr_sparse_wiring_eval.argtypes = [C.c_int, gp, sz, C.c_uint32, C.c_uint32] + [u64p] * 8
+    lib.zk_gkr_sparse_wiring_eval.restype = C.c_int
+    lib.zk_sparse_circuit_evaluate.argtypes = [C.c_int, gp, szp, sz, u32p, u64p, sz, u64p]
+    lib.zk_sparse_circuit_evaluate.restype = C.c_int
+    lib._sparse_declared = True
+    return lib
+
+
+def gates_array(gate_rows):
+    """(n, 4) uint64 array of (left, right, out, op) rows -> ctypes gate array (zero-copy for big circuits)"""
+    rows = np.ascontiguousarray(gate_rows, np.uint64).reshape(-1, 4)
+    return rows, rows.ctypes.data_as(C.POINTER(_Gate))
+
+
+class SparseProof:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def sparse_prove(field, layer_gate_rows, out_bits, inputs):
+    """layer_gate_rows: list (layer 0 = output layer) of (n_l, 4) arrays of (left, right, out, op)."""
+    lib = _decl_sparse()
+    Lm = limbs(field)
+    x = np.ascontiguousarray(inputs, np.uint64).reshape(-1, Lm)
+    nl = len(layer_gate_rows)
+    rows = np.ascontiguousarray(np.concatenate([np.asarray(r, np.uint64).reshape(-1, 4) for r in layer_gate_rows]))
+    counts = (C.c_size_t * nl)(*[len(r) for r in layer_gate_rows])
+    ob = (C.c_uint32 * nl)(*out_bits)
+    in_bits = [out_bits[i + 1] if i + 1 < nl else x.shape[0].bit_length() - 1 for i in range(nl)]
+    rounds = [2 * k for k in in_bits]
+    tot = sum(rounds)
+    out = np.zeros((1 << out_bits[0], Lm), np.uint64)
+    cs = np.zeros(Lm, np.uint64)
+    claims = np.zeros((nl, Lm), np.uint64)
+    co = np.zeros((tot, 3, Lm), np.uint64)
+    ch = np.zeros((tot, Lm), np.uint64)
+    wb = np.zeros((max(nl - 1, 1), Lm), np.uint64)
+    wc = np.zeros((max(nl - 1, 1), Lm), np.uint64)
+    ra = np.zeros((out_bits[0], Lm), np.uint64)
+    ms = (C.c_float * nl)()
+    L.check(lib.zk_gkr_sparse_prove(field, rows.ctypes.data_as(C.POINTER(_Gate)), counts, nl, ob, L.p64(x), x.shape[0], L.p64(out),
+                                    L.p64(cs), L.p64(claims), L.p64(co), L.p64(ch), L.p64(wb), L.p64(wc), L.p64(ra), ms))
+    return SparseProof(circuit_output=out, claimed_sum=cs, layer_claims=claims, coeffs=co, challenges=ch, wb_evals=wb[: nl - 1],
+                       wc_evals=wc[: nl - 1], output_challenges=ra, rounds=rounds, in_bits=in_bits, ms_layers=list(ms))
+
+
+def sparse_wiring_eval(field, gate_rows, out_bits, in_bits, pa, rb, rc, alpha=None, beta=None, pb=None):
+    lib = _decl_sparse()
+    Lm = limbs(field)
+    rows = np.ascontiguousarray(gate_rows, np.uint64).reshape(-1, 4)
+    a, m = np.zeros(Lm, np.uint64), np.zeros(Lm, np.uint64)
+    c = lambda v: L.p64(np.ascontiguousarray(v, np.uint64)) if v is not None else None
+    L.check(lib.zk_gkr_sparse_wiring_eval(field, rows.ctypes.data_as(C.POINTER(_Gate)), rows.shape[0], out_bits, in_bits, c(alpha), c(pa),
+                                          c(beta), c(pb), c(rb), c(rc), L.p64(a), L.p64(m)))
+    return a, m
+
+
+def sparse_verify(field, layer_gate_rows, out_bits, proof, inputs):
+    """The verifier of gkr_protocol.rs:146-236 for the sparse representation (the wiring predicates are
+    evaluated from the gate lists in O(#gates) on the GPU).  Used by tests and the config-4 bench."""
+    from .mle import MultilinearPolynomial
+    from .sumcheck import Transcript, SumcheckProverProof, verify as sumcheck_verify
+    from . import sharded as S
+    S._declare_host()
+    lib = L.lib()
+    Lm = limbs(field)
+
+    def mul(a, b):
+        o = np.zeros(Lm, np.uint64)
+        L.check(lib.zk_fe_mul(field, L.p64(np.ascontiguousarray(a)), L.p64(np.ascontiguousarray(b)), L.p64(o)))
+        return o
+
+    nl = len(layer_gate_rows)
+    t = Transcript()
+    w0 = MultilinearPolynomial(field, proof.circuit_output)
+    t.append(w0.convert_to_bytes())
+    ra = np.stack([t.random_challenge_as_field_element(field) for _ in range(out_bits[0])])
+    claim = w0.evaluate(ra)
+    alpha = beta = None
+    pa, pb = ra, None
+    off = 0
+    x = MultilinearPolynomial(field, inputs)
+    for l in range(nl):
+        if not np.array_equal(claim, proof.layer_claims[l]):
+            return False
+        r = proof.rounds[l]
+        res = sumcheck_verify(SumcheckProverProof(proof.layer_claims[l], proof.coeffs[off:off + r], None), t, field)
+        if not res.is_proof_valid:
+            return False
+        ch = res.random_challenges
+        k = r // 2
+        if l + 1 < nl:
+            wb, wc = proof.wb_evals[l], proof.wc_evals[l]
+        else:
+            wb, wc = x.evaluate(ch[:k]), x.evaluate(ch[k:])
+        add_r, mul_r = sparse_wiring_eval(field, layer_gate_rows[l], out_bits[l], k, pa, ch[:k], ch[k:], alpha, beta, pb)
+        expect = S.fe_add(field, mul(add_r, S.fe_add(field, wb, wc)), mul(mul_r, mul(wb, wc)))
+        if not np.array_equal(expect, res.last_claimed_sum):
+            return False
+        t.append(S.fe_to_bytes_be(field, wb))
+        alpha = t.random_challenge_as_field_element(field)
+        t.append(S.fe_to_bytes_be(field, wc))
+        beta = t.random_challenge_as_field_element(field)
+        claim = S.fe_add(field, mul(alpha, wb), mul(beta, wc))
+        pa, pb = ch[:k], ch[k:]
+        off += r
+    return True
