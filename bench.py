@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-msm", action="store_true", help="skip the secondary 2^log-n MSM measurement")
     ap.add_argument("--msm-reps", type=int, default=3)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="debug: run the N>1 code path with every rank on cuda:0 over gloo (one-GPU boxes)")
     args = ap.parse_args()
 
     import numpy as np
@@ -39,10 +41,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: zkmle_amd has no CPU fallback")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     _lib.check(zk.lib().zk_init(local_rank))
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     field = zk.FR381
     n = 1 << args.log_n
@@ -81,7 +88,7 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if args.rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -90,7 +97,7 @@ def main():
     algo_bytes = 96.0 * half                               # per launch: 2 x 32 B read + 32 B write per mul
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
     result = {
-        "metric": "field-mul/s (2^24 MLE fold)", "value": value, "unit": "field-mul/s", "n_gpus": world,
+        "metric": f"field-mul/s (2^{args.log_n} MLE fold)", "value": value, "unit": "field-mul/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (BLS12-381 Fr, Montgomery)",
         "data": "synthetic",
@@ -107,7 +114,7 @@ def main():
             result["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
         result["roofline"]["traffic_source"] = "profiles/r1/fold_2p24_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)"
     if world > 1:
-        result["exchange"] = sumcheck_round_exchange(zk, table, out, r, world, local_rank)
+        result["exchange"] = sumcheck_round_exchange(zk, table, out, r, world, local_rank, args.rehearse)
     if not args.no_msm:
         result["msm"] = msm_leg(zk, args, rank, world, local_rank)
     if rank == 0 and not args.no_cpu_baseline:
@@ -118,7 +125,7 @@ def main():
         dist.destroy_process_group()
 
 
-def sumcheck_round_exchange(zk, table, out, r, world, local_rank):
+def sumcheck_round_exchange(zk, table, out, r, world, local_rank, rehearse=False):
     """The path's real exchange step: one fused sumcheck round (fold + half sums) per rank plus ONE
     all-gather of the 2 partial sums over RCCL and the host reduction mod p.  Reported beside the fold metric."""
     import time
@@ -126,7 +133,7 @@ def sumcheck_round_exchange(zk, table, out, r, world, local_rank):
     import torch
     import torch.distributed as dist
     S = zk.sharded
-    comm = S.Comm(device=torch.device("cuda", local_rank))
+    comm = S.Comm(device=None if rehearse else torch.device("cuda", local_rank))
     reps = 50
     dist.barrier()
     torch.cuda.synchronize()
@@ -137,8 +144,9 @@ def sumcheck_round_exchange(zk, table, out, r, world, local_rank):
         tot = np.stack([S.fe_sum(table.field, g[:, 0]), S.fe_sum(table.field, g[:, 1])])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    return {"what": "fused sumcheck round on a 2^24 shard + all-gather of 2 field elements per rank (RCCL) + host reduce",
-            "ms_per_round": dt * 1e3, "bytes_per_rank_per_round": 64, "collective": "all_gather", "backend": "nccl (RCCL)"}
+    return {"what": "fused sumcheck round on this rank's shard + all-gather of 2 field elements per rank (RCCL) + host reduce",
+            "ms_per_round": dt * 1e3, "bytes_per_rank_per_round": 64, "collective": "all_gather",
+            "backend": "gloo (rehearsal)" if rehearse else "nccl (RCCL)"}
 
 
 def msm_leg(zk, args, rank, world, local_rank):
@@ -155,7 +163,7 @@ def msm_leg(zk, args, rank, world, local_rank):
     scalars = zk.MultilinearPolynomial.random(0, n, 0x5EED0003 + 97 * rank)
     out, st = zk.kzg.msm(scalars, bases, 0, True)           # warm-up
     S = zk.sharded
-    comm = S.Comm(device=torch.device("cuda", local_rank)) if world > 1 else None
+    comm = S.Comm(device=None if args.rehearse else torch.device("cuda", local_rank)) if world > 1 else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -171,7 +179,7 @@ def msm_leg(zk, args, rank, world, local_rank):
         dist.barrier()
     dt = (time.perf_counter() - t0) / args.msm_reps
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if args.rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     st = stats[-1]

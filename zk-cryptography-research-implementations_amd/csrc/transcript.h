@@ -18,6 +18,18 @@ class Keccak256 {
   public:
     Keccak256() { memset(a_, 0, sizeof a_); fill_ = 0; }
     void update(const uint8_t *data, size_t n) {
+        // whole blocks straight from the caller's buffer: 17 little-endian lanes per block (the table absorb of
+        // Prover::prove, prover.rs:38-39, is 32 * 2^n bytes of sequential sponge input)
+        while (fill_ == 0 && n >= kRate) {
+            for (int i = 0; i < 17; i++) {
+                uint64_t w;
+                memcpy(&w, data + 8 * i, 8);
+                a_[i] ^= w;            // x86-64 / little-endian hosts only (the library targets ROCm hosts)
+            }
+            permute();
+            data += kRate;
+            n -= kRate;
+        }
         while (n) {
             size_t room = kRate - fill_;
             size_t take = n < room ? n : room;
