@@ -13,6 +13,11 @@
 
 using namespace zk;
 
+namespace zk {
+int circuit_evaluate_device(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const size_t *widths,
+                            const uint64_t *inputs, uint64_t *evals);
+}
+
 namespace {
 
 struct TableDeleter { void operator()(zk_table *t) const { zk_table_free(t); } };
@@ -96,23 +101,12 @@ template <class F> int circuit_evaluate(const zk_gate *gates, const size_t *gate
     ce.eoff.assign(nlayers + 2, 0);
     ce.lsz.assign(nlayers + 1, 0);
     for (size_t l = 0; l < nlayers; l++) ce.goff[l + 1] = ce.goff[l] + gate_counts[l];
-    for (size_t l = 0; l < nlayers; l++) ce.lsz[l] = layer_len(gates + ce.goff[l], gate_counts[l]);
+    for (size_t l = 0; l < nlayers; l++) ce.lsz[l] = layer_len(gates + ce.goff[l], gate_counts[l]);   // :73-80
     ce.lsz[nlayers] = ninputs;
     for (size_t l = 0; l <= nlayers; l++) ce.eoff[l + 1] = ce.eoff[l] + ce.lsz[l];
     ce.evals.assign(ce.eoff[nlayers + 1] * L64, 0);
-    memcpy(ce.evals.data() + ce.eoff[nlayers] * L64, inputs, ninputs * L64 * 8);      // :69
-    for (size_t l = nlayers; l-- > 0;) {                                               // :72 layers.iter().rev()
-        const uint64_t *cur = ce.evals.data() + ce.eoff[l + 1] * L64;
-        uint64_t *res = ce.evals.data() + ce.eoff[l] * L64;
-        for (size_t k = 0; k < gate_counts[l]; k++) {                                  // :86
-            const zk_gate &g = gates[ce.goff[l] + k];
-            if (g.left >= ce.lsz[l + 1] || g.right >= ce.lsz[l + 1]) return ZK_E_RANGE;
-            Fe<F> a = load_el<F>(cur + g.left * L64), b = load_el<F>(cur + g.right * L64);
-            Fe<F> v = g.op == 0 ? fe_add<F>(a, b) : fe_mul<F>(a, b);                   // :90-93
-            store_el<F>(res + g.out * L64, fe_add<F>(load_el<F>(res + g.out * L64), v));   // :96 +=
-        }
-    }
-    return ZK_OK;
+    // one kernel launch per layer, lane per output wire (gates grouped by output: the += of :96)
+    return circuit_evaluate_device(F::ID, gates, gate_counts, nlayers, ce.lsz.data(), inputs, ce.evals.data());
 }
 
 template <class F> int add_mul_mle(const zk_gate *g, size_t ngates, size_t layer_index, TablePtr &add_i, TablePtr &mul_i) {
@@ -311,6 +305,7 @@ size_t zk_circuit_eval_size(const zk_gate *gates, const size_t *gate_counts, siz
 int zk_circuit_evaluate(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *inputs,
                         size_t ninputs, size_t *layer_sizes, uint64_t *evals) {
     if (!gates || !gate_counts || !inputs || !layer_sizes || !evals) return ZK_E_ARG;
+    ZK_TRY(require_device());
     ZK_DISPATCH_FIELD(field, {
         CircuitEval ce;
         ZK_TRY((circuit_evaluate<F>(gates, gate_counts, nlayers, inputs, ninputs, ce)));

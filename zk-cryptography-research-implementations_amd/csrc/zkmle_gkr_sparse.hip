@@ -368,6 +368,48 @@ template <class F> int wiring_eval(const zk_gate *g, size_t ngates, uint32_t out
 
 }  // namespace
 
+namespace zk {
+// Circuit::evaluate (arithmetic_circuit.rs:65-109) on the GPU for arbitrary layer widths: widths[l] outputs for
+// layer l (max output index + 1, :73-80), widths[nlayers] = ninputs.  evals = layer 0 .. inputs concatenated.
+int circuit_evaluate_device(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const size_t *widths,
+                            const uint64_t *inputs, uint64_t *evals) {
+    ZK_DISPATCH_FIELD(field, {
+        const size_t L64 = F::N / 2, esz = 4 * F::N;
+        std::vector<size_t> eoff(nlayers + 2, 0), goff(nlayers + 1, 0);
+        for (size_t l = 0; l <= nlayers; l++) eoff[l + 1] = eoff[l] + widths[l];
+        for (size_t l = 0; l < nlayers; l++) goff[l + 1] = goff[l] + gate_counts[l];
+        DevBuf dev;
+        ZK_TRY(dev.alloc(eoff[nlayers + 1] * esz));
+        ZK_HIP(hipMemcpy((char *)dev.p + eoff[nlayers] * esz, inputs, widths[nlayers] * esz, hipMemcpyHostToDevice));
+        for (size_t l = nlayers; l-- > 0;) {
+            size_t n = gate_counts[l], nout = widths[l], nin = widths[l + 1];
+            std::vector<uint32_t> out(n), left(n), right(n), op(n), order, start;
+            for (size_t i = 0; i < n; i++) {
+                const zk_gate &g = gates[goff[l] + i];
+                if (g.left >= nin || g.right >= nin || g.out >= nout) return ZK_E_RANGE;     // index panic in the reference
+                out[i] = (uint32_t)g.out; left[i] = (uint32_t)g.left; right[i] = (uint32_t)g.right; op[i] = g.op ? 1u : 0u;
+            }
+            group_by(out, nout, order, start);
+            DevBuf d_out, d_left, d_right, d_op, d_ord, d_st;
+            ZK_TRY(d_out.upload(out.data(), n * 4));
+            ZK_TRY(d_left.upload(left.data(), n * 4));
+            ZK_TRY(d_right.upload(right.data(), n * 4));
+            ZK_TRY(d_op.upload(op.data(), n * 4));
+            ZK_TRY(d_ord.upload(order.data(), n * 4));
+            ZK_TRY(d_st.upload(start.data(), start.size() * 4));
+            GateArrays ga{(const uint32_t *)d_out.p, (const uint32_t *)d_left.p, (const uint32_t *)d_right.p, (const uint32_t *)d_op.p};
+            circuit_layer_kernel<F><<<blocks(nout), kBlock>>>(ga, (const uint32_t *)d_ord.p, (const uint32_t *)d_st.p, nout,
+                                                               (const char *)dev.p + eoff[l + 1] * esz, (char *)dev.p + eoff[l] * esz);
+            ZK_HIP(hipGetLastError());
+            ZK_HIP(hipDeviceSynchronize());
+        }
+        ZK_HIP(hipMemcpy(evals, dev.p, eoff[nlayers + 1] * esz, hipMemcpyDeviceToHost));
+        (void)L64;
+    });
+    return ZK_OK;
+}
+}  // namespace zk
+
 extern "C" {
 
 int zk_gkr_sparse_prove(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint32_t *out_bits,
