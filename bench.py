@@ -117,6 +117,8 @@ def main():
         result["exchange"] = sumcheck_round_exchange(zk, table, out, r, world, local_rank, args.rehearse)
     if not args.no_msm:
         result["msm"] = msm_leg(zk, args, rank, world, local_rank)
+        if rank == 0 and not args.no_cpu_baseline:
+            result["msm"]["cpu_baseline"] = cpu_baseline_msm(zk)
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(zk, field)
     if rank == 0:
@@ -192,6 +194,23 @@ def msm_leg(zk, args, rank, world, local_rank):
             "workload": f"2^{args.log_n} random Fr scalars x synthetic affine bases [a + i d]G per GPU; slice-sharded, all-gather of {world} points"}
 
 
+def cpu_baseline_msm(zk):
+    """the oracle's restatement of the reference's NAIVE commit (one 255-bit double-and-add per term,
+    multilinear_kzg.rs:37-42) on 2^10 terms, one host core; the reference has no MSM routine"""
+    import numpy as np
+    from oracle import oracle as O
+    from zkmle_amd import _lib
+    n = 1 << 10
+    sc = np.zeros((n, 4), np.uint64)
+    _lib.check(zk.lib().zk_host_fill_random(0, 0x5EED0003, 0, n, _lib.p64(sc)))
+    a = zk.from_ints(0, [0x5EED0003])[0]
+    d = zk.from_ints(0, [0x9E3779B97F4A7C15])[0]
+    pts = zk.G1Bases.synthetic(n, a, d).points()
+    secs = O.bench_commit_naive(sc, pts)
+    return {"value": n / secs, "unit": "terms/s", "cores": 1, "kind": "port",
+            "sample": f"naive double-and-add commit of 2^10 terms (same generator), 1 thread; linear in the number of terms"}
+
+
 def cpu_baseline(zk, field):
     """the oracle's reference-faithful single-thread fold, timed on this host on a bounded sample"""
     import numpy as np
@@ -203,7 +222,7 @@ def cpu_baseline(zk, field):
     _lib.check(zk.lib().zk_host_fill_random(field, 0x5EED0005, 0, n, _lib.p64(tab)))
     r = tab[3].copy()
     O.bench_fold(field, tab, r, 1)
-    reps = 20
+    reps = 300                                  # ~10 s of single-core work
     secs = O.bench_fold(field, tab, r, reps)
     return {"value": (n // 2) * reps / secs, "unit": "field-mul/s", "cores": 1, "kind": "port",
             "sample": f"{reps} folds of a 2^{log_n}-entry Fr table (same generator), reference allocation pattern, 1 thread"}

@@ -70,6 +70,28 @@ template <class F> __global__ void k_fold_u(const void *__restrict__ in, void *_
     zk::Fe<F> lo = zk::fe_load<F>(in, i), hi = zk::fe_load<F>(in, i + half);
     zk::fe_store<F>(out, i, zk::fe_add<F>(lo, zk::fe_mul_u_pre<F>(ru, zk::fe_sub<F>(hi, lo))));
 }
+template <class F> __device__ __forceinline__ zk::Fe<F> nt_load(const void *base, size_t idx);
+template <class F> __device__ __forceinline__ void nt_store(void *base, size_t idx, const zk::Fe<F> &a) {
+    uint32_t *p = reinterpret_cast<uint32_t *>(base) + idx * F::N;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) __builtin_nontemporal_store(a.l[k], p + k);
+}
+template <class F, int EPT, bool NTS, bool NTL> __global__ void k_fold_u2(const void *__restrict__ in, void *__restrict__ out, size_t half, zk::Ufe<F> ru) {
+    size_t chunk = half / EPT;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chunk) return;
+    zk::Fe<F> lo[EPT], hi[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        lo[e] = NTL ? nt_load<F>(in, i + e * chunk) : zk::fe_load<F>(in, i + e * chunk);
+        hi[e] = NTL ? nt_load<F>(in, i + e * chunk + half) : zk::fe_load<F>(in, i + e * chunk + half);
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        zk::Fe<F> o = zk::fe_add<F>(lo[e], zk::fe_mul_u_pre<F>(ru, zk::fe_sub<F>(hi[e], lo[e])));
+        if (NTS) nt_store<F>(out, i + e * chunk, o); else zk::fe_store<F>(out, i + e * chunk, o);
+    }
+}
 // the fold's memory pattern with trivial arithmetic (2 streams in, 1 out, 32 B per lane)
 template <class F> __global__ void k_stream3(const void *in, void *out, size_t half) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -214,6 +236,19 @@ int main(int argc, char **argv) {
                 int grid = (int)((half + 255) / 256);
                 float ms = time_ms([&] { k_fold_u<zk::Fr381><<<grid, 256>>>(in, out, half, ru); }, 20);
                 printf("{\"kernel\": \"fold_u29\", \"grid\": %d, \"ms\": %.4f, \"GBps\": %.1f}\n", grid, ms, 96.0 * half / (ms * 1e-3) / 1e9);
+            }
+            {
+                zk::Ufe<zk::Fr381> ru = zk::u_from_limbs32<zk::Fr381>(r);
+#define RUN_U2(EPT, NTS, NTL, BS)                                                                                 \
+                {                                                                                                 \
+                    int grid = (int)((half / EPT + BS - 1) / BS);                                                 \
+                    float ms = time_ms([&] { k_fold_u2<zk::Fr381, EPT, NTS, NTL><<<grid, BS>>>(in, out, half, ru); }, 30); \
+                    printf("{\"kernel\": \"fold_u2\", \"ept\": %d, \"nt_store\": %d, \"nt_load\": %d, \"block\": %d, \"ms\": %.4f, \"GBps\": %.1f}\n", EPT, (int)NTS, (int)NTL, BS, ms, 96.0 * half / (ms * 1e-3) / 1e9); \
+                    fflush(stdout);                                                                               \
+                }
+                RUN_U2(1, false, false, 256) RUN_U2(1, true, false, 256) RUN_U2(1, true, true, 256) RUN_U2(1, false, true, 256)
+                RUN_U2(2, false, false, 256) RUN_U2(2, true, false, 256) RUN_U2(1, false, false, 512) RUN_U2(1, false, false, 1024)
+                RUN_U2(1, false, false, 128) RUN_U2(4, false, false, 256) RUN_U2(2, true, true, 512)
             }
             RUN_V(1, false, 256) RUN_V(1, false, 512) RUN_V(1, false, 1024) RUN_V(1, false, 128) RUN_V(1, false, 64)
             RUN_V(2, false, 256) RUN_V(4, false, 256) RUN_V(2, false, 128) RUN_V(2, false, 512)
