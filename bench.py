@@ -99,10 +99,11 @@ def main():
     result = {
         "metric": f"field-mul/s (2^{args.log_n} MLE fold)", "value": value, "unit": "field-mul/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (BLS12-381 Fr, Montgomery)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": f"{args.log_n}-variable MLE fold (partial_evaluate var 0), BLS12-381 Fr, "
                                f"2^{args.log_n}-entry table per GPU", "log_n": args.log_n, "field": "bls12_381_fr",
+                   "arithmetic": "255-bit Montgomery field, 8 x u32 limbs in HBM, products as 29-bit-limb v_mad_u64_u32 scans",
                    "sharding": "low-bit shard per rank, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "traffic": None, "kernel": "fold0_kernel<Fr381>", "kernel_ms": kern_ms,

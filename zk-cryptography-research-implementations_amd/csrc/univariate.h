@@ -39,4 +39,25 @@ template <class F> inline std::vector<Fe<F>> lagrange_interpolate(const std::vec
     return out;
 }
 
+// The interpolation nodes of the sumcheck are always 0..d, so the d+1 basis polynomials l_i(x) are the same in
+// every round: build them once per prover call (d+1 inversions) and turn each round's evaluations into
+// coefficients with (d+1)^2 multiplications.  Same field elements as lagrange_interpolate (exact arithmetic).
+template <class F> inline std::vector<std::vector<Fe<F>>> lagrange_basis_matrix(const std::vector<Fe<F>> &xs) {
+    size_t n = xs.size();
+    std::vector<std::vector<Fe<F>>> basis(n);
+    for (size_t i = 0; i < n; i++) {
+        std::vector<Fe<F>> ys(n, fe_zero<F>());
+        ys[i] = fe_one<F>();
+        basis[i] = lagrange_interpolate<F>(xs, ys);
+    }
+    return basis;
+}
+template <class F> inline std::vector<Fe<F>> interpolate_with_basis(const std::vector<std::vector<Fe<F>>> &basis, const std::vector<Fe<F>> &ys) {
+    size_t n = ys.size();
+    std::vector<Fe<F>> out(n, fe_zero<F>());
+    for (size_t i = 0; i < n; i++)
+        for (size_t d = 0; d < n; d++) out[d] = fe_add<F>(out[d], fe_mul<F>(ys[i], basis[i][d]));
+    return out;
+}
+
 }  // namespace zk

@@ -209,6 +209,7 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
     ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
     std::vector<Fe<F>> xs(npts), evals(npts);
     for (size_t i = 0; i < npts; i++) xs[i] = fe_from_u64<F>(i);       // :46-48
+    const std::vector<std::vector<Fe<F>>> basis = lagrange_basis_matrix<F>(xs);   // nodes 0..d never change
     SumPolyTables tabs{};
     for (size_t k = 0; k < ntab; k++) tabs.in[k] = tables[k]->dptr;
     // round 0 evaluations
@@ -224,7 +225,7 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
     char *dst = (char *)bufA.p, *other = (char *)bufB.p;
     size_t cl = len;
     for (unsigned round = 0; round < nvars; round++) {                 // :37
-        std::vector<Fe<F>> co = lagrange_interpolate<F>(xs, evals);    // :49-50
+        std::vector<Fe<F>> co = interpolate_with_basis<F>(basis, evals);   // :49-50 (same coefficients, no per-round inversions)
         for (size_t i = 0; i < npts; i++) {
             tr.append_le<F>(co[i]);                                    // :52 little-endian coefficients
             store_el<F>(round_coeffs + ((size_t)round * npts + i) * L64, co[i]);
