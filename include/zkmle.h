@@ -266,6 +266,16 @@ int zk_gkr_sparse_prove(int field, const zk_gate *gates, const size_t *gate_coun
                         uint64_t *circuit_output, uint64_t *claimed_sum, uint64_t *layer_claims,
                         uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals,
                         uint64_t *output_challenges /* out_bits[0] elements */, float *ms_layers /* nlayers, may be NULL */);
+/* a circuit compiled once (gate lists uploaded and grouped by left / right / output index) and reused by
+ * any number of proofs: the per-circuit preprocessing is O(#gates) host work that does not belong in a proof */
+typedef struct zk_sparse_circuit zk_sparse_circuit;
+int zk_sparse_circuit_new(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint32_t *out_bits,
+                          size_t ninputs, zk_sparse_circuit **out);
+int zk_sparse_circuit_free(zk_sparse_circuit *c);
+int zk_gkr_sparse_prove_compiled(int field, const zk_sparse_circuit *c, const uint64_t *inputs, size_t ninputs,
+                                 uint64_t *circuit_output, uint64_t *claimed_sum, uint64_t *layer_claims,
+                                 uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals,
+                                 uint64_t *output_challenges, float *ms_layers);
 /* independent evaluation of the wiring predicates at a point (the verifier's O(#gates) work):
  * add_r = sum_{add gates} w_g eq(rb, left_g) eq(rc, right_g), same for mul, with
  * w_g = alpha eq(pa, out_g) + beta eq(pb, out_g)  (layer 0: alpha = 1, beta = 0, pa = output challenges). */

@@ -233,13 +233,15 @@ int build_layers(const zk_gate *gates, const size_t *gate_counts, size_t nlayers
     return ZK_OK;
 }
 
-template <class F> int sparse_prove(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint32_t *out_bits,
-                                    const uint64_t *inputs, size_t ninputs, uint64_t *circuit_output, uint64_t *claimed_sum,
-                                    uint64_t *layer_claims, uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals,
-                                    uint64_t *output_challenges, float *ms_layers) {
+template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_t *inputs, size_t ninputs, uint64_t *circuit_output,
+                                    uint64_t *claimed_sum, uint64_t *layer_claims, uint64_t *coeffs, uint64_t *challenges,
+                                    uint64_t *wb_evals, uint64_t *wc_evals, uint64_t *output_challenges, float *ms_layers) {
     const size_t L64 = F::N / 2, esz = 4 * F::N;
-    std::vector<LayerDev> layers;
-    ZK_TRY(build_layers(gates, gate_counts, nlayers, out_bits, ninputs, layers));
+    const size_t nlayers = layers.size();
+    std::vector<uint32_t> out_bits_v(nlayers);
+    for (size_t l = 0; l < nlayers; l++) out_bits_v[l] = layers[l].out_bits;
+    const uint32_t *out_bits = out_bits_v.data();
+    if (ninputs != ((size_t)1 << layers[nlayers - 1].in_bits)) return ZK_E_LEN_MISMATCH;
     std::vector<TablePtr> W;
     ZK_TRY((evaluate_layers<F>(layers, inputs, ninputs, W)));                        // Circuit::evaluate (arithmetic_circuit.rs:65-109)
     size_t nout = (size_t)1 << out_bits[0];
@@ -368,6 +370,10 @@ template <class F> int wiring_eval(const zk_gate *g, size_t ngates, uint32_t out
 
 }  // namespace
 
+struct zk_sparse_circuit {
+    std::vector<LayerDev> layers;
+};
+
 namespace zk {
 // Circuit::evaluate (arithmetic_circuit.rs:65-109) on the GPU for arbitrary layer widths: widths[l] outputs for
 // layer l (max output index + 1, :73-80), widths[nlayers] = ninputs.  evals = layer 0 .. inputs concatenated.
@@ -420,10 +426,36 @@ int zk_gkr_sparse_prove(int field, const zk_gate *gates, const size_t *gate_coun
         !output_challenges || nlayers == 0)
         return ZK_E_ARG;
     if (nlayers > 1 && (!wb_evals || !wc_evals)) return ZK_E_ARG;
+    zk_sparse_circuit *c = nullptr;
+    ZK_TRY(zk_sparse_circuit_new(gates, gate_counts, nlayers, out_bits, ninputs, &c));
+    int rc = zk_gkr_sparse_prove_compiled(field, c, inputs, ninputs, circuit_output, claimed_sum, layer_claims, coeffs, challenges, wb_evals,
+                                          wc_evals, output_challenges, ms_layers);
+    zk_sparse_circuit_free(c);
+    return rc;
+}
+int zk_sparse_circuit_new(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint32_t *out_bits, size_t ninputs,
+                          zk_sparse_circuit **out) {
+    if (!gates || !gate_counts || !out_bits || !out || nlayers == 0) return ZK_E_ARG;
     if (out_bits[0] == 0) return ZK_E_ARG;      // a single output wire is padded to two by the caller (gkr_protocol.rs:43-47)
     ZK_TRY(require_device());
-    ZK_DISPATCH_FIELD(field, return sparse_prove<F>(gates, gate_counts, nlayers, out_bits, inputs, ninputs, circuit_output, claimed_sum,
-                                                    layer_claims, coeffs, challenges, wb_evals, wc_evals, output_challenges, ms_layers));
+    std::unique_ptr<zk_sparse_circuit> c(new zk_sparse_circuit());
+    ZK_TRY(build_layers(gates, gate_counts, nlayers, out_bits, ninputs, c->layers));
+    *out = c.release();
+    return ZK_OK;
+}
+int zk_sparse_circuit_free(zk_sparse_circuit *c) {
+    delete c;
+    return ZK_OK;
+}
+int zk_gkr_sparse_prove_compiled(int field, const zk_sparse_circuit *c, const uint64_t *inputs, size_t ninputs, uint64_t *circuit_output,
+                                 uint64_t *claimed_sum, uint64_t *layer_claims, uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals,
+                                 uint64_t *wc_evals, uint64_t *output_challenges, float *ms_layers) {
+    if (!c || !inputs || !circuit_output || !claimed_sum || !layer_claims || !coeffs || !challenges || !output_challenges) return ZK_E_ARG;
+    if (c->layers.size() > 1 && (!wb_evals || !wc_evals)) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    std::vector<LayerDev> &layers = const_cast<zk_sparse_circuit *>(c)->layers;   // read-only use of device buffers
+    ZK_DISPATCH_FIELD(field, return sparse_prove<F>(layers, inputs, ninputs, circuit_output, claimed_sum, layer_claims, coeffs, challenges,
+                                                    wb_evals, wc_evals, output_challenges, ms_layers));
     return ZK_OK;
 }
 int zk_gkr_sparse_wiring_eval(int field, const zk_gate *layer_gates, size_t ngates, uint32_t out_bits, uint32_t in_bits, const uint64_t *alpha,

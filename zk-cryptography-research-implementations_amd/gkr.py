@@ -234,6 +234,12 @@ def _decl_sparse():
     lib.zk_gkr_sparse_wiring_eval.restype = C.c_int
     lib.zk_sparse_circuit_evaluate.argtypes = [C.c_int, gp, szp, sz, u32p, u64p, sz, u64p]
     lib.zk_sparse_circuit_evaluate.restype = C.c_int
+    lib.zk_sparse_circuit_new.argtypes = [gp, szp, sz, u32p, sz, C.POINTER(L.vp)]
+    lib.zk_sparse_circuit_new.restype = C.c_int
+    lib.zk_sparse_circuit_free.argtypes = [L.vp]
+    lib.zk_sparse_circuit_free.restype = C.c_int
+    lib.zk_gkr_sparse_prove_compiled.argtypes = [C.c_int, L.vp, u64p, sz] + [u64p] * 8 + [fp]
+    lib.zk_gkr_sparse_prove_compiled.restype = C.c_int
     lib._sparse_declared = True
     return lib
 
@@ -249,15 +255,38 @@ class SparseProof:
         self.__dict__.update(kw)
 
 
-def sparse_prove(field, layer_gate_rows, out_bits, inputs):
-    """layer_gate_rows: list (layer 0 = output layer) of (n_l, 4) arrays of (left, right, out, op)."""
+class SparseCircuit:
+    """a circuit compiled once for the sparse prover (gate lists in HBM, grouped by left / right / output index)"""
+
+    def __init__(self, layer_gate_rows, out_bits, ninputs):
+        lib = _decl_sparse()
+        nl = len(layer_gate_rows)
+        rows = np.ascontiguousarray(np.concatenate([np.asarray(r, np.uint64).reshape(-1, 4) for r in layer_gate_rows]))
+        counts = (C.c_size_t * nl)(*[len(r) for r in layer_gate_rows])
+        ob = (C.c_uint32 * nl)(*out_bits)
+        h = C.c_void_p()
+        L.check(lib.zk_sparse_circuit_new(rows.ctypes.data_as(C.POINTER(_Gate)), counts, nl, ob, ninputs, C.byref(h)))
+        self._h, self.out_bits, self.ninputs, self.nlayers = h, list(out_bits), ninputs, nl
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                L.lib().zk_sparse_circuit_free(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+
+def sparse_prove(field, layer_gate_rows, out_bits, inputs, circuit=None):
+    """layer_gate_rows: list (layer 0 = output layer) of (n_l, 4) arrays of (left, right, out, op);
+    pass a SparseCircuit as `circuit` to reuse a compiled circuit."""
     lib = _decl_sparse()
     Lm = limbs(field)
     x = np.ascontiguousarray(inputs, np.uint64).reshape(-1, Lm)
-    nl = len(layer_gate_rows)
-    rows = np.ascontiguousarray(np.concatenate([np.asarray(r, np.uint64).reshape(-1, 4) for r in layer_gate_rows]))
-    counts = (C.c_size_t * nl)(*[len(r) for r in layer_gate_rows])
-    ob = (C.c_uint32 * nl)(*out_bits)
+    if circuit is None:
+        circuit = SparseCircuit(layer_gate_rows, out_bits, x.shape[0])
+    out_bits = circuit.out_bits
+    nl = circuit.nlayers
     in_bits = [out_bits[i + 1] if i + 1 < nl else x.shape[0].bit_length() - 1 for i in range(nl)]
     rounds = [2 * k for k in in_bits]
     tot = sum(rounds)
@@ -270,8 +299,8 @@ def sparse_prove(field, layer_gate_rows, out_bits, inputs):
     wc = np.zeros((max(nl - 1, 1), Lm), np.uint64)
     ra = np.zeros((out_bits[0], Lm), np.uint64)
     ms = (C.c_float * nl)()
-    L.check(lib.zk_gkr_sparse_prove(field, rows.ctypes.data_as(C.POINTER(_Gate)), counts, nl, ob, L.p64(x), x.shape[0], L.p64(out),
-                                    L.p64(cs), L.p64(claims), L.p64(co), L.p64(ch), L.p64(wb), L.p64(wc), L.p64(ra), ms))
+    L.check(lib.zk_gkr_sparse_prove_compiled(field, circuit._h, L.p64(x), x.shape[0], L.p64(out), L.p64(cs), L.p64(claims), L.p64(co),
+                                             L.p64(ch), L.p64(wb), L.p64(wc), L.p64(ra), ms))
     return SparseProof(circuit_output=out, claimed_sum=cs, layer_claims=claims, coeffs=co, challenges=ch, wb_evals=wb[: nl - 1],
                        wc_evals=wc[: nl - 1], output_challenges=ra, rounds=rounds, in_bits=in_bits, ms_layers=list(ms))
 
