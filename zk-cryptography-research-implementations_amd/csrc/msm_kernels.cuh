@@ -232,6 +232,125 @@ __global__ void eq_expand_kernel(const void *__restrict__ in, void *__restrict__
 }
 
 
+// ---- two-level scatter for wide windows (c >= 12) --------------------------------------------------------------
+// The single-pass scatter above writes 4-byte entries to 2^(c-1) open runs per window at once: at 2^24 terms it is
+// write-amplification bound (6.4 ms).  Here entries are first partitioned by the HIGH bits of the bucket id
+// (<= 128 partitions per window; each workgroup sorts a 2048-element tile in LDS and writes whole runs), then each
+// partition (a contiguous range of 256 buckets, ~0.5 MB of entries) is finished by one workgroup whose 256 open
+// runs stay L2-resident.  A partition occupies the same index range in the intermediate and in the final array.
+constexpr unsigned kFineBits = 8;
+constexpr int kPartTile = 2048;      // elements per LDS tile
+constexpr int kPartBlock = 256;
+
+// A1: phist[(w * nh + h) * nchunks + chunk] = entries of chunk whose bucket has high part h
+__global__ void msm_part_hist_kernel(const uint16_t *__restrict__ digits, size_t n, unsigned c, unsigned nchunks, size_t chunk_len,
+                                     uint32_t *__restrict__ phist) {
+    __shared__ uint32_t cnt[128];
+    unsigned lb = (c - 1) < kFineBits ? (c - 1) : kFineBits, nh = 1u << (c - 1 - lb);
+    unsigned chunk = blockIdx.x % nchunks, w = blockIdx.x / nchunks;
+    for (unsigned h = threadIdx.x; h < nh; h += blockDim.x) cnt[h] = 0;
+    __syncthreads();
+    size_t lo = (size_t)chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint16_t *d = digits + (size_t)w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        unsigned enc = d[i];
+        if (enc) atomicAdd(&cnt[(digit_bucket(enc, c) - 1) >> lb], 1u);
+    }
+    __syncthreads();
+    for (unsigned h = threadIdx.x; h < nh; h += blockDim.x) phist[((size_t)w * nh + h) * nchunks + chunk] = cnt[h];
+}
+// A2: per (w, h): absolute start of every chunk's run = partition start + exclusive prefix over chunks
+__global__ void msm_part_scan_kernel(uint32_t *__restrict__ phist, unsigned nwin, unsigned c, unsigned nchunks,
+                                     const uint64_t *__restrict__ starts, uint64_t *__restrict__ poff) {
+    unsigned lb = (c - 1) < kFineBits ? (c - 1) : kFineBits, nh = 1u << (c - 1 - lb), nb = 1u << (c - 1);
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)nwin * nh) return;
+    unsigned w = id / nh, h = id % nh;
+    uint64_t run = starts[(size_t)w * nb + ((size_t)h << lb)];
+    for (unsigned ch = 0; ch < nchunks; ch++) {
+        uint32_t v = phist[id * nchunks + ch];
+        poff[id * nchunks + ch] = run;
+        run += v;
+    }
+}
+// A3: partition the chunk's entries by h with whole-run writes (tile-local counting sort in LDS)
+__global__ void __launch_bounds__(kPartBlock) msm_part_scatter_kernel(const uint16_t *__restrict__ digits, size_t n, unsigned c, unsigned nchunks,
+                                                                      size_t chunk_len, const uint64_t *__restrict__ poff,
+                                                                      uint32_t *__restrict__ part_e, uint8_t *__restrict__ part_l) {
+    __shared__ uint64_t cursor[128];
+    __shared__ uint32_t cnt[128], binstart[128];
+    __shared__ uint32_t stage_e[kPartTile];
+    __shared__ uint8_t stage_l[kPartTile], stage_h[kPartTile];
+    constexpr int PER = kPartTile / kPartBlock;
+    unsigned lb = (c - 1) < kFineBits ? (c - 1) : kFineBits, nh = 1u << (c - 1 - lb);
+    unsigned nwin = gridDim.x / nchunks;
+    unsigned chunk = blockIdx.x % nchunks, w = blockIdx.x / nchunks;
+    for (unsigned h = threadIdx.x; h < nh; h += blockDim.x) cursor[h] = poff[((size_t)w * nh + h) * nchunks + chunk];
+    size_t lo = (size_t)chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint16_t *d = digits + (size_t)w * n;
+    for (size_t base = lo; base < hi; base += kPartTile) {
+        for (unsigned h = threadIdx.x; h < nh; h += blockDim.x) cnt[h] = 0;
+        __syncthreads();
+        uint32_t ent[PER], rank[PER];
+        uint16_t hl[PER];                       // h << 8 | low ; 0xffff = skip
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            size_t i = base + (size_t)k * kPartBlock + threadIdx.x;
+            hl[k] = 0xffffu;
+            if (i < hi) {
+                unsigned enc = d[i];
+                if (enc) {
+                    unsigned b = digit_bucket(enc, c) - 1, h = b >> lb;
+                    unsigned neg = (enc & 0x8000u) && (w + 1 < nwin);
+                    ent[k] = (uint32_t)i | (neg << 31);
+                    hl[k] = (uint16_t)((h << 8) | (b & ((1u << lb) - 1u)));
+                    rank[k] = atomicAdd(&cnt[h], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (unsigned h = 0; h < nh; h++) { binstart[h] = run; run += cnt[h]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+            if (hl[k] != 0xffffu) {
+                unsigned h = hl[k] >> 8, pos = binstart[h] + rank[k];
+                stage_e[pos] = ent[k];
+                stage_l[pos] = (uint8_t)(hl[k] & 0xffu);
+                stage_h[pos] = (uint8_t)h;
+            }
+        __syncthreads();
+        uint32_t total = binstart[nh - 1] + cnt[nh - 1];
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+            unsigned h = stage_h[i];
+            uint64_t dst = cursor[h] + (i - binstart[h]);
+            part_e[dst] = stage_e[i];
+            part_l[dst] = stage_l[i];
+        }
+        __syncthreads();
+        for (unsigned h = threadIdx.x; h < nh; h += blockDim.x) cursor[h] += cnt[h];
+        __syncthreads();
+    }
+}
+// B: one workgroup per partition (w, h): final placement by the low bits, cursors in LDS
+__global__ void msm_fine_scatter_kernel(const uint32_t *__restrict__ part_e, const uint8_t *__restrict__ part_l, unsigned c,
+                                        const uint64_t *__restrict__ starts, uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t cursor[1u << kFineBits];          // relative to the partition start (a partition holds < 2^32 entries)
+    unsigned lb = (c - 1) < kFineBits ? (c - 1) : kFineBits, nh = 1u << (c - 1 - lb), nb = 1u << (c - 1);
+    unsigned w = blockIdx.x / nh, h = blockIdx.x % nh;
+    size_t first_bucket = (size_t)w * nb + ((size_t)h << lb);
+    uint64_t pstart = starts[first_bucket], pend = starts[first_bucket + (1u << lb)];
+    for (unsigned l = threadIdx.x; l < (1u << lb); l += blockDim.x) cursor[l] = (uint32_t)(starts[first_bucket + l] - pstart);
+    __syncthreads();
+    for (uint64_t i = pstart + threadIdx.x; i < pend; i += blockDim.x) {
+        uint32_t pos = atomicAdd(&cursor[part_l[i]], 1u);
+        sorted[pstart + pos] = part_e[i];
+    }
+}
+
 #endif  // ZK_MSM_LIGHT_KERNELS
 
 // ---- heavy kernels live in their own translation units (compiled in parallel); launchers: ----------

@@ -120,9 +120,32 @@ int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c,
     ZK_HIP(hipMemcpy(tail, (uint32_t *)seg_starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
     uint32_t nseg = tail[0], max_segs = tail[1];
     ZK_TRY(sorted.alloc((entries ? entries : 1) * 4));
-    msm_scatter_kernel<<<nwin * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len,
-                                                                   (const uint32_t *)hist.p, (const uint64_t *)starts.p, (uint32_t *)sorted.p);
-    ZK_HIP(hipGetLastError());
+    if (c >= 12 && n >= ((size_t)1 << 22)) {   // measured r1: wins at 2^24 (8.6 -> 5.4 ms), loses below 2^21
+        // two-level scatter: partition by the high bits of the bucket id (tile-sorted whole-run writes), then finish
+        // each 256-bucket partition with one workgroup (msm_kernels.cuh)
+        const unsigned lb = (unsigned)(c - 1) < kFineBits ? (unsigned)(c - 1) : kFineBits, nh = 1u << (c - 1 - lb);
+        size_t pchunk_len = (n + 255) / 256;
+        if (pchunk_len < (size_t)kPartTile) pchunk_len = kPartTile;
+        const unsigned pchunks = (unsigned)((n + pchunk_len - 1) / pchunk_len);
+        DevBuf phist, poff, part_e, part_l;
+        ZK_TRY(phist.alloc((size_t)nwin * nh * pchunks * 4));
+        ZK_TRY(poff.alloc((size_t)nwin * nh * pchunks * 8));
+        ZK_TRY(part_e.alloc((entries ? entries : 1) * 4));
+        ZK_TRY(part_l.alloc(entries ? entries : 1));
+        msm_part_hist_kernel<<<nwin * pchunks, 256>>>((const uint16_t *)digits.p, n, (unsigned)c, pchunks, pchunk_len, (uint32_t *)phist.p);
+        msm_part_scan_kernel<<<(unsigned)(((size_t)nwin * nh + 255) / 256), 256>>>((uint32_t *)phist.p, nwin, (unsigned)c, pchunks,
+                                                                                  (const uint64_t *)starts.p, (uint64_t *)poff.p);
+        msm_part_scatter_kernel<<<nwin * pchunks, kPartBlock>>>((const uint16_t *)digits.p, n, (unsigned)c, pchunks, pchunk_len,
+                                                                 (const uint64_t *)poff.p, (uint32_t *)part_e.p, (uint8_t *)part_l.p);
+        msm_fine_scatter_kernel<<<nwin * nh, kSortBlock>>>((const uint32_t *)part_e.p, (const uint8_t *)part_l.p, (unsigned)c,
+                                                           (const uint64_t *)starts.p, (uint32_t *)sorted.p);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipDeviceSynchronize());      // the intermediates are freed on scope exit
+    } else {
+        msm_scatter_kernel<<<nwin * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len,
+                                                                       (const uint32_t *)hist.p, (const uint64_t *)starts.p, (uint32_t *)sorted.p);
+        ZK_HIP(hipGetLastError());
+    }
     ZK_TRY(ev.mark());
     // bucket sums
     ZK_TRY(partials.alloc(((size_t)nseg ? nseg : 1) * sizeof(G1Xyzz)));
