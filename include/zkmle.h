@@ -54,6 +54,7 @@ int zk_device_count(int *count);
 int zk_init(int device);              /* select the device for the calling thread's later calls */
 int zk_field_limbs(int field);        /* u64 limbs per element (4 or 6), negative on bad field */
 int zk_device_synchronize(void);
+int zk_release_cached_memory(void);   /* frees the library's cached per-call scratch (MSM workspaces) on the current device */
 
 /* ---- device-resident tables ----------------------------------------------------------------
  * MultilinearPolynomial<F>{evaluated_values: Vec<F>}  evaluation_form.rs:7-18 */

@@ -34,6 +34,12 @@ int scratch(size_t bytes, void **out);
 // pinned host staging for small results (a few field elements)
 int host_staging(size_t bytes, void **out);
 
+// Caching device allocator for per-call scratch (the MSM allocates several GB per call; hipMalloc / hipFree of
+// such blocks costs milliseconds).  Freed blocks are kept per device and reused by later calls of similar size;
+// zk_release_cached_memory() returns them to the driver.
+int pool_alloc(size_t bytes, void **out);
+void pool_free(void *p);
+
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 inline unsigned ilog2(size_t x) { unsigned k = 0; while (x >>= 1) k++; return k; }
 inline int field_limbs64(int field) { return field == ZK_FQ381 ? 6 : (field >= 0 && field <= 3 ? 4 : -1); }

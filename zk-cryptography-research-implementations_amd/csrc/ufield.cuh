@@ -201,7 +201,32 @@ template <class F> ZK_HD Ufe<F> umul(const Ufe<F> &a, const Ufe<F> &b) {
     for (int i = 0; i < L; i++) u_row<F>(T, a, b.l[i]);
     return u_normalize_columns<F>(T);
 }
-template <class F> ZK_HD Ufe<F> usqr(const Ufe<F> &a) { return umul<F>(a, a); }
+// a^2 / 2^(29 L): the row scan with the symmetric products taken once.  At step t the live column j holds
+// absolute weight j + t, so a_j a_t (j > t) is added doubled at step t only; every contribution to the column
+// that the Montgomery step consumes (weight t) comes from steps <= t/2, so T[0] is complete when it is used.
+// L (L + 1) / 2 multiply-adds instead of L^2 for the a * a half.
+template <class F> ZK_HD Ufe<F> usqr(const Ufe<F> &a) {
+    constexpr int L = UParams<F>::L;
+    uint64_t T[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) T[j] = 0;
+#pragma unroll
+    for (int t = 0; t < L; t++) {
+        uint32_t at = a.l[t], at2 = at << 1;
+        T[t] += (uint64_t)at * at;
+#pragma unroll
+        for (int j = t + 1; j < L; j++) T[j] += (uint64_t)a.l[j] * at2;
+        uint32_t m = ((uint32_t)T[0] * UParams<F>::INV) & UMASK;
+#pragma unroll
+        for (int j = 0; j < L; j++) T[j] += (uint64_t)m * UParams<F>::p(j);
+        uint64_t carry = T[0] >> UB;
+#pragma unroll
+        for (int j = 0; j + 1 < L; j++) T[j] = T[j + 1];
+        T[L - 1] = 0;
+        T[0] += carry;
+    }
+    return u_normalize_columns<F>(T);
+}
 
 // ---- additive operations on unreduced values ----------------------------------------------------------------
 template <class F> ZK_HD Ufe<F> u_zero() {

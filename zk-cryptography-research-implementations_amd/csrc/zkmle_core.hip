@@ -71,6 +71,38 @@ int host_staging(size_t bytes, void **out) {
     return ZK_OK;
 }
 
+struct PoolBlock { void *p; size_t cap; int dev; bool busy; };
+static std::vector<PoolBlock> g_pool;
+static size_t g_pool_bytes = 0;
+static const size_t kPoolLimit = (size_t)48 << 30;      // cached + in-use scratch per process
+
+int pool_alloc(size_t bytes, void **out) {
+    if (bytes == 0) bytes = 16;
+    int dev = 0;
+    ZK_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        PoolBlock *best = nullptr;
+        for (PoolBlock &b : g_pool)
+            if (!b.busy && b.dev == dev && b.cap >= bytes && b.cap <= 2 * bytes + (1u << 20) && (!best || b.cap < best->cap)) best = &b;
+        if (best) { best->busy = true; *out = best->p; return ZK_OK; }
+    }
+    if (g_pool_bytes + bytes > kPoolLimit) ZK_TRY(zk_release_cached_memory());
+    void *p = nullptr;
+    ZK_HIP(hipMalloc(&p, bytes));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pool.push_back(PoolBlock{p, bytes, dev, true});
+    g_pool_bytes += bytes;
+    *out = p;
+    return ZK_OK;
+}
+void pool_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (PoolBlock &b : g_pool)
+        if (b.p == p) { b.busy = false; return; }
+}
+
 template <class F> static Fe<F> load_host(const uint64_t *src) {
     Fe<F> e;
     memcpy(e.l, src, sizeof(uint32_t) * F::N);
@@ -129,6 +161,22 @@ int zk_init(int device) {
 int zk_field_limbs(int field) {
     int n = field_limbs64(field);
     return n < 0 ? ZK_E_ARG : n;
+}
+int zk_release_cached_memory(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ZK_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_pool.size();) {
+        if (!g_pool[i].busy && g_pool[i].dev == dev) {
+            (void)hipFree(g_pool[i].p);
+            g_pool_bytes -= g_pool[i].cap;
+            g_pool[i] = g_pool.back();
+            g_pool.pop_back();
+        } else {
+            i++;
+        }
+    }
+    return ZK_OK;
 }
 int zk_device_synchronize(void) {
     ZK_TRY(require_device());

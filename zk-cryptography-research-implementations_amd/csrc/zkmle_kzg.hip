@@ -26,10 +26,11 @@ struct zk_kzg_opening_key {
 
 namespace {
 
-struct DevBuf {
+struct DevBuf {     // per-call scratch from the caching pool (context.h)
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { ZK_HIP(hipMalloc(&p, bytes ? bytes : 16)); return ZK_OK; }
+    ~DevBuf() { pool_free(p); }
+    int alloc(size_t bytes) { return pool_alloc(bytes, &p); }
+    void release() { pool_free(p); p = nullptr; }
 };
 struct Events {
     hipEvent_t e[8];
@@ -166,8 +167,8 @@ int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c,
     const uint32_t *cur_starts = (const uint32_t *)seg_starts.p;
     for (int lvl = 0; max_segs > kGroup; lvl++) {
         DevBuf &np = lvl_partials[lvl & 1], &ns = lvl_starts[lvl & 1];
-        if (ns.p) { ZK_HIP(hipFree(ns.p)); ns.p = nullptr; }
-        if (np.p) { ZK_HIP(hipFree(np.p)); np.p = nullptr; }
+        ns.release();
+        np.release();
         ZK_TRY(ns.alloc((nbuckets + 2) * 4));
         msm_regroup_scan_kernel<<<1, kSortBlock>>>(cur_starts, nbuckets, kGroup, (uint32_t *)ns.p);
         ZK_HIP(hipGetLastError());
