@@ -50,5 +50,10 @@ struct zk_table {
     int field;
     size_t len;
     void *dptr;
-    bool owned;
+    int owned;      // 0 = view of caller memory (zk_table_wrap), 1 = hipMalloc, 2 = block of the scratch pool
 };
+
+namespace zk {
+// a temporary table backed by the caching pool (internal provers: dozens of same-sized temporaries per proof)
+int table_alloc_pooled(int field, size_t len, zk_table **out);
+}

@@ -103,6 +103,16 @@ void pool_free(void *p) {
         if (b.p == p) { b.busy = false; return; }
 }
 
+int table_alloc_pooled(int field, size_t len, zk_table **out) {
+    int limbs = field_limbs64(field);
+    if (limbs < 0 || !out || len == 0) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    void *d = nullptr;
+    ZK_TRY(pool_alloc(len * (size_t)limbs * 8, &d));
+    *out = new zk_table{field, len, d, 2};
+    return ZK_OK;
+}
+
 template <class F> static Fe<F> load_host(const uint64_t *src) {
     Fe<F> e;
     memcpy(e.l, src, sizeof(uint32_t) * F::N);
@@ -191,7 +201,7 @@ int zk_table_alloc(int field, size_t len, zk_table **out) {
     ZK_TRY(require_device());
     void *d = nullptr;
     ZK_HIP(hipMalloc(&d, len * (size_t)limbs * 8));
-    *out = new zk_table{field, len, d, true};
+    *out = new zk_table{field, len, d, 1};
     return ZK_OK;
 }
 int zk_table_upload(int field, const uint64_t *host, size_t len, zk_table **out) {
@@ -217,7 +227,8 @@ int zk_table_download(const zk_table *t, uint64_t *host) {
 }
 int zk_table_free(zk_table *t) {
     if (!t) return ZK_OK;
-    if (t->owned && t->dptr) ZK_HIP(hipFree(t->dptr));
+    if (t->owned == 1 && t->dptr) ZK_HIP(hipFree(t->dptr));
+    if (t->owned == 2) pool_free(t->dptr);
     delete t;
     return ZK_OK;
 }
@@ -226,7 +237,7 @@ int zk_table_field(const zk_table *t) { return t ? t->field : ZK_E_ARG; }
 void *zk_table_device_ptr(zk_table *t) { return t ? t->dptr : nullptr; }
 int zk_table_wrap(int field, void *device_ptr, size_t len, zk_table **out) {
     if (field_limbs64(field) < 0 || !device_ptr || !out || len == 0) return ZK_E_ARG;
-    *out = new zk_table{field, len, device_ptr, false};
+    *out = new zk_table{field, len, device_ptr, 0};
     return ZK_OK;
 }
 int zk_table_clone(const zk_table *t, zk_table **out) {
@@ -397,9 +408,9 @@ int zk_mle_evaluate(const zk_table *t, const uint64_t *values, size_t nvalues, u
     }
     // ping-pong between two halves of one scratch allocation (len/2 + len/4 elements)
     zk_table *a = nullptr, *b = nullptr;
-    ZK_TRY(zk_table_alloc(t->field, t->len / 2, &a));
+    ZK_TRY(table_alloc_pooled(t->field, t->len / 2, &a));
     int rc = ZK_OK;
-    if (t->len >= 4) rc = zk_table_alloc(t->field, t->len / 4, &b);
+    if (t->len >= 4) rc = table_alloc_pooled(t->field, t->len / 4, &b);
     const zk_table *cur = t;
     zk_table *dst = a, *other = b;
     for (size_t i = 0; i < nvalues && rc == ZK_OK; i++) {

@@ -28,7 +28,7 @@ template <class F> void store_el(uint64_t *dst, const Fe<F> &e) { memcpy(dst, e.
 
 int alloc_table(int field, size_t len, TablePtr &out) {
     zk_table *t = nullptr;
-    ZK_TRY(zk_table_alloc(field, len, &t));
+    ZK_TRY(table_alloc_pooled(field, len, &t));
     out.reset(t);
     return ZK_OK;
 }

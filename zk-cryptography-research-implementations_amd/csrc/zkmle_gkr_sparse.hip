@@ -28,8 +28,8 @@ struct TableDeleter { void operator()(zk_table *t) const { zk_table_free(t); } }
 using TablePtr = std::unique_ptr<zk_table, TableDeleter>;
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { ZK_HIP(hipMalloc(&p, bytes ? bytes : 16)); return ZK_OK; }
+    ~DevBuf() { pool_free(p); }                     // per-call scratch from the caching pool (context.h)
+    int alloc(size_t bytes) { return pool_alloc(bytes, &p); }
     int upload(const void *src, size_t bytes) { ZK_TRY(alloc(bytes)); if (bytes) ZK_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice)); return ZK_OK; }
 };
 template <class F> Fe<F> load_el(const uint64_t *src) { Fe<F> e; memcpy(e.l, src, 4 * F::N); return e; }
@@ -37,7 +37,7 @@ template <class F> void store_el(uint64_t *dst, const Fe<F> &e) { memcpy(dst, e.
 
 int alloc_table(int field, size_t len, TablePtr &out) {
     zk_table *t = nullptr;
-    ZK_TRY(zk_table_alloc(field, len, &t));
+    ZK_TRY(table_alloc_pooled(field, len, &t));
     out.reset(t);
     return ZK_OK;
 }

@@ -23,8 +23,8 @@ template <class F> void store_el(uint64_t *dst, const Fe<F> &e) { memcpy(dst, e.
 
 struct DevBuf {   // RAII device allocation
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { ZK_HIP(hipMalloc(&p, bytes ? bytes : 16)); return ZK_OK; }
+    ~DevBuf() { pool_free(p); }                     // per-call scratch from the caching pool (context.h)
+    int alloc(size_t bytes) { return pool_alloc(bytes, &p); }
 };
 
 // absorb convert_to_bytes(table) (evaluation_form.rs:35-43) chunk by chunk:
