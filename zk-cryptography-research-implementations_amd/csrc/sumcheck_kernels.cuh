@@ -58,7 +58,7 @@ __device__ __forceinline__ void write_partials(Fe<F> (&acc)[NFAC + 1], Fe<F> *sh
 
 // tables of `2 * half` entries; partials[t * gridDim.x + block]
 template <class F, int NFAC>
-__global__ void round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials) {
+__global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials) {
     __shared__ Fe<F> sh[kBlock / 64];
     Fe<F> acc[NFAC + 1];
 #pragma unroll
@@ -81,7 +81,7 @@ __global__ void round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, v
 // tables of 4q entries in, 2q out; lane i folds outputs i and i+q of every table, then uses them
 // as the (lo, hi) pair of the NEXT round.
 template <class F, int NFAC>
-__global__ void fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials) {
+__global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials) {
     __shared__ Fe<F> sh[kBlock / 64];
     Fe<F> acc[NFAC + 1];
 #pragma unroll
