@@ -148,8 +148,10 @@ def sumcheck_round_exchange(zk, table, out, r, world, local_rank, rehearse=False
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    from zkmle_amd import _lib
+    sums = np.zeros((2, 4), np.uint64)
     for _ in range(reps):
-        folded, sums = table.fold_half_sums(r)
+        _lib.check(zk.lib().zk_mle_fold_half_sums(table._h, _lib.p64(r), out._h, _lib.p64(sums), None))   # resident buffers
         g = comm.all_gather(sums)
         tot = np.stack([S.fe_sum(table.field, g[:, 0]), S.fe_sum(table.field, g[:, 1])])
     torch.cuda.synchronize()
