@@ -11,6 +11,9 @@
  */
 #include "zk_internal.h"
 #include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define EL(base, i, n) ((base) + (size_t)(i) * (size_t)(n))
 static int is_pow2(size_t x) { return x && !(x & (x - 1)); }
@@ -367,6 +370,41 @@ double orc_bench_fold(int field, const uint64_t *table, size_t len, const uint64
         free(copy);
     }
     return now_s() - t0;
+}
+/* best-effort multi-core variant: the same per-element arithmetic with the output
+ * indices split over OpenMP threads (variable 0 only); returns seconds, *threads_used receives the team size */
+double orc_bench_fold_mt(int field, const uint64_t *table, size_t len, const uint64_t *r, int reps, int *threads_used) {
+    const field_t *F = orc_fld(field);
+    if (!F) return -1.0;
+    fe v;
+    fe_load(F, &v, r);
+    size_t n = (size_t)F->n, half = len / 2;
+    uint64_t *res = (uint64_t *)malloc(8 * n * half);
+    int used = 1;
+    double t0 = now_s();
+    for (int k = 0; k < reps; k++) {
+#pragma omp parallel
+        {
+#ifdef _OPENMP
+#pragma omp single
+            used = omp_get_num_threads();
+#endif
+#pragma omp for schedule(static)
+            for (long i = 0; i < (long)half; i++) {
+                fe y1, y2, d, t, o;
+                fe_load(F, &y1, table + (size_t)i * n);
+                fe_load(F, &y2, table + ((size_t)i + half) * n);
+                fe_sub(F, &d, &y2, &y1);
+                fe_mul(F, &t, &v, &d);
+                fe_add(F, &o, &y1, &t);
+                fe_store(F, res + (size_t)i * n, &o);
+            }
+        }
+    }
+    double dt = now_s() - t0;
+    free(res);
+    if (threads_used) *threads_used = used;
+    return dt;
 }
 double orc_bench_commit_naive(const uint64_t *values, size_t len, const uint64_t *g1_points) {
     uint64_t out[12];

@@ -47,6 +47,7 @@ def lib():
         _lib.orc_transcript_new.restype = C.c_void_p
         _lib.orc_bench_fold.restype = C.c_double
         _lib.orc_bench_commit_naive.restype = C.c_double
+        _lib.orc_bench_fold_mt.restype = C.c_double
         for n in ("orc_num_layer_variables", "orc_wiring_index", "orc_circuit_eval_size", "orc_gkr_rounds"):
             getattr(_lib, n).restype = C.c_size_t
     return _lib
@@ -542,6 +543,14 @@ def gkr_prove_succinct(layers, inputs, g1_points, n_g2=None):
 def bench_fold(field, table, r, reps):
     t = _arr(field, table)
     return lib().orc_bench_fold(field, _p(t), C.c_size_t(t.shape[0]), _p(_arr(field, r)), reps)
+
+
+def bench_fold_mt(field, table, r, reps):
+    """-> (seconds, threads used): OpenMP over the output indices"""
+    t = _arr(field, table)
+    used = C.c_int(0)
+    secs = lib().orc_bench_fold_mt(field, _p(t), C.c_size_t(t.shape[0]), _p(_arr(field, r)), reps, C.byref(used))
+    return secs, used.value
 
 
 def bench_commit_naive(values, points):

@@ -191,6 +191,7 @@ int orc_kzg_quotients(const uint64_t *values, size_t len, const uint64_t *openin
 /* --- CPU baseline timing helpers (bench.py cpu_baseline leg) --------------- */
 /* fold the table `reps` times with the reference's allocation pattern; returns seconds */
 double orc_bench_fold(int field, const uint64_t *table, size_t len, const uint64_t *r, int reps);
+double orc_bench_fold_mt(int field, const uint64_t *table, size_t len, const uint64_t *r, int reps, int *threads_used);
 double orc_bench_commit_naive(const uint64_t *values, size_t len, const uint64_t *g1_points);
 
 #ifdef __cplusplus
