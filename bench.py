@@ -234,13 +234,19 @@ def cpu_baseline(zk, field):
     O.bench_fold(field, tab, r, 1)
     reps = 300                                  # ~10 s of single-core work
     secs = O.bench_fold(field, tab, r, reps)
-    mt_reps = 300
+    mt_reps = 100
     O.bench_fold_mt(field, tab, r, 5)
     mt_secs, threads = O.bench_fold_mt(field, tab, r, mt_reps)
-    return {"value": (n // 2) * reps / secs, "unit": "field-mul/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} folds of a 2^{log_n}-entry Fr table (same generator), reference allocation pattern, 1 thread",
-            "all_cores": {"value": (n // 2) * mt_reps / mt_secs, "unit": "field-mul/s", "cores": threads, "kind": "port",
-                          "sample": f"{mt_reps} folds of the same table, OpenMP over output indices (the reference itself is single-threaded)"}}
+    base = {"value": (n // 2) * reps / secs, "unit": "field-mul/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} folds of a 2^{log_n}-entry Fr table (same generator), reference allocation pattern, 1 thread"}
+    mt_value = (n // 2) * mt_reps / mt_secs
+    if mt_value > base["value"]:
+        base["all_cores"] = {"value": mt_value, "unit": "field-mul/s", "cores": threads, "kind": "port",
+                             "sample": f"{mt_reps} folds of the same table, OpenMP over output indices (the reference itself is single-threaded)"}
+    else:
+        base["all_cores"] = {"value": None, "cores": threads,
+                             "note": "OpenMP run was slower than one thread under this host's CPU quota; not reported"}
+    return base
 
 
 if __name__ == "__main__":
