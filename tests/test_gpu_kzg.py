@@ -138,6 +138,48 @@ def test_msm_linear_checksum_2p16(zk):
     assert O.g1_affine_ints(got) == M.g1_mul(M.G1, k)
 
 
+def test_msm_config3_size_2p20(zk):
+    """BASELINE config 3: 2^20-term MSM; checked with the O(N) linear identity for bases [a + i d] G"""
+    n = 1 << 20
+    a, d = rand_fr(zk, 2, 21)
+    bases = zk.G1Bases.synthetic(n, a, d)
+    scalars = zk.MultilinearPolynomial.random(0, n, 0x5EED0003)
+    got, stats = zk.kzg.msm(scalars, bases, with_stats=True)
+    assert stats["window_bits"] == 16 and stats["terms"] == n
+    s = scalars.to_ints()
+    ai, di = O.to_ints(O.FR381, np.stack([a, d]))
+    k = (ai * sum(s) + di * sum(i * v for i, v in enumerate(s))) % R
+    assert O.g1_affine_ints(got) == M.g1_mul(M.G1, k)
+    # every window size lands on the same group element
+    for c in (11, 14):
+        assert np.array_equal(zk.kzg.msm(scalars, bases, window_bits=c), got)
+
+
+def test_commit_open_n16(zk):
+    """KZG commit + open of a 2^16 table: evaluation, proof count and the identity sum_i Q_i(tau)(tau_i - x_i) = f(tau) - v
+    with the prover's own group elements (pi_i = [Q_i(tau)] G checked through the scalar identity on G)"""
+    rng = random.Random(16)
+    nv = 16
+    taus_i = [rng.randrange(R) for _ in range(nv)]
+    taus = zk.from_ints(0, taus_i)
+    setup = zk.TrustedSetup.initialize_setup(taus)
+    poly = zk.MultilinearPolynomial.random(0, 1 << nv, 1616)
+    vals = poly.evaluated_values
+    f_tau = O.to_ints(O.FR381, O.evaluate(O.FR381, vals, taus))[0]
+    c = zk.MultilinearKZG.commit_to_polynomial(poly, setup)
+    assert O.g1_affine_ints(c) == M.g1_mul(M.G1, f_tau)
+    opening_i = [rng.randrange(R) for _ in range(nv)]
+    opening = zk.from_ints(0, opening_i)
+    proof = zk.MultilinearKZG.open_and_prove(poly, setup, opening)
+    v = O.to_ints(O.FR381, O.evaluate(O.FR381, vals, opening))[0]
+    assert zk.to_ints(0, proof.evaluation) == [v] and len(proof.proofs) == nv
+    # sum_i (tau_i - x_i) * pi_i  ==  [f(tau) - v] G   (the pairing equation projected to G1, tau known)
+    acc = np.zeros(12, np.uint64)
+    for i in range(nv):
+        acc = O.g1_add(acc, O.g1_mul_fr(proof.proofs[i], O.from_ints(O.FR381, [(taus_i[i] - opening_i[i]) % R])[0]))
+    assert O.g1_affine_ints(acc) == M.g1_mul(M.G1, (f_tau - v) % R)
+
+
 def test_commit_open_random_n10(zk):
     """larger random KZG instance: commit == [f(tau)] G, proofs == [Q_i(tau)] G, identity sum"""
     rng = random.Random(4)
