@@ -131,8 +131,18 @@ int zk_uni_evaluate(int field, const uint64_t *coeffs, size_t n, const uint64_t 
 int zk_uni_lagrange_interpolate(int field, const uint64_t *xs, const uint64_t *ys, size_t n, uint64_t *out); /* :74 */
 
 /* ---- basic sumcheck (sumcheck_protocol/src/basic_sumcheck) ------------------------------------- */
+/* Host-clock split of the last zk_sumcheck_basic_prove / zk_sumcheck_gkr_prove / zk_sumcheck_gkr_rounds call made on the
+ * calling thread: `ms_absorb` = the whole-table transcript absorb (prover.rs:38-39, sequential Keccak on the host),
+ * `ms_rounds` = every round (kernels + device-side transcript) up to the single synchronisation. */
+typedef struct {
+    uint32_t rounds;
+    float ms_absorb, ms_rounds;
+} zk_sumcheck_stats;
+int zk_sumcheck_last_stats(zk_sumcheck_stats *out);
+
 /* Prover::init + Prover::prove  prover.rs:22-71.  The table stays in HBM; per round one fused
- * fold + half-sums kernel; the host owns the transcript.  round_polys: nvars*2 elements
+ * fold + half-sums kernel; after the table absorb the transcript lives on the device (one host
+ * synchronisation per proof, csrc/dev_transcript.cuh).  round_polys: nvars*2 elements
  * (SumcheckProof.round_univariate_polynomials); challenges (nvars) is diagnostic, may be NULL. */
 int zk_sumcheck_basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys,
                             uint64_t *challenges);

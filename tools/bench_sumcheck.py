@@ -13,6 +13,7 @@ for lg in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "20,24").split
     prover = zk.Prover.init(0, poly)
     prover.prove()                                    # warm-up
     t0 = time.time(); proof = prover.prove(); t_prove = time.time() - t0
+    st = zk.sumcheck.last_stats()
     t0 = time.time(); ok = zk.Verifier.init().verify(proof); t_verify = time.time() - t0
     # rounds only: the same fused kernels without the table absorb
     cur = poly
@@ -23,14 +24,17 @@ for lg in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "20,24").split
         cur, sums = cur.fold_half_sums(r)
     t_rounds = time.time() - t0
     print(json.dumps({"prover": "basic sumcheck (Prover::prove)", "log_n": lg, "prove_s": t_prove, "rounds_only_s": t_rounds,
-                      "absorb_and_rest_s": t_prove - t_rounds, "verify_s": t_verify, "verified": bool(ok),
+                      "absorb_and_rest_s": t_prove - t_rounds,
+                      "prove_absorb_ms": st["ms_absorb"], "prove_rounds_ms": st["ms_rounds"], "verify_s": t_verify, "verified": bool(ok),
                       "field_mul_per_s_rounds": (n - 1) / t_rounds}), flush=True)
     if lg <= 22:
+      for lgg in sorted({12, 16, lg}):
+        n = 1 << lgg
         tabs = [[zk.MultilinearPolynomial.random(0, n, 10 * p + f) for f in range(2)] for p in range(2)]
         sp = zk.SumPolynomial([zk.ProductPolynomial(t) for t in tabs])
         claimed = sp.add_polynomials_element_wise().sum()
         zk.sumcheck.prove(sp, claimed, zk.Transcript())
         t0 = time.time(); res = zk.sumcheck.prove(sp, claimed, zk.Transcript()); t_g = time.time() - t0
         v = zk.sumcheck.verify(res, zk.Transcript(), 0)
-        print(json.dumps({"prover": "GKR sumcheck (4 tables)", "log_n": lg, "prove_s": t_g, "verified": bool(v.is_proof_valid),
-                          "field_mul_per_s": 5 * 2 * n / t_g}), flush=True)
+        print(json.dumps({"prover": "GKR sumcheck (4 tables)", "log_n": lgg, "prove_s": t_g, "rounds_ms": zk.sumcheck.last_stats()["ms_rounds"],
+                          "verified": bool(v.is_proof_valid), "field_mul_per_s": 5 * 2 * n / t_g}), flush=True)

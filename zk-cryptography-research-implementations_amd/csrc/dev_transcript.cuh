@@ -1,0 +1,252 @@
+// dev_transcript.cuh -- the Fiat-Shamir transcript kept ON THE DEVICE between sumcheck rounds.
+//
+// A sumcheck round is "reduce the partials -> round message -> absorb -> challenge -> fold by the challenge".
+// With the sponge on the host every round costs a device->host->device round trip (~100 us on MI355X, more than
+// the kernels of all but the first few rounds).  Here the one-workgroup finish kernel of a round also runs the
+// transcript step, writes the challenge to device memory, and the next round's fold kernel reads it from there:
+// the host enqueues all rounds back to back and synchronises once per sumcheck.  The host sponge
+// (transcript.h) exports / imports its 25-lane state + fill, so large absorbs (tables) stay on the CPU.
+//
+// Semantics restated: transcripts/src/fiat_shamir/fiat_shamir_transcript.rs:22-43
+//   append -> update ; sample -> finalize a CLONE, absorb the 32-byte digest ; challenge = from_le_bytes_mod_order.
+// Round messages: basic sumcheck prover.rs:50-58 (two sums, big-endian), GKR sumcheck
+// sumcheck_gkr_protocol.rs:41-55 (Lagrange coefficients over 0..d, little-endian).
+#pragma once
+#include "sumcheck_kernels.cuh"
+
+#ifndef TS          // timing hooks, defined by tools/microbench_finish.hip only
+#define TS(k)
+#endif
+
+namespace zk {
+
+struct DevSponge {          // mirrors Keccak256's private state (transcript.h)
+    uint64_t a[25];
+    uint32_t fill;          // bytes absorbed into the current block, < 136
+    uint32_t pad_;
+};
+
+constexpr int kFinishBlock = 1024;   // 16 waves: <= 4 partials per lane at the largest reduction grid
+
+__device__ __constant__ const uint64_t kKeccakRC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
+    0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+    0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
+    0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+
+__device__ __constant__ const uint8_t kKeccakRho[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, unsigned s) { return s ? (x << s) | (x >> (64 - s)) : x; }
+
+// LDS exchange inside ONE wave: the LDS pipeline serves a wave's requests in order, so lanes see each other's earlier
+// writes; the fences only stop the compiler from moving LDS accesses across the exchange point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Keccak-f[1600] by one wave, uniform control flow: lane l owns state lane (x, y) = (l % 5, l / 5) of l % 25 (lanes
+// 25..63 mirror lanes 0..24 and store the same values).  Per round two LDS exchanges: the column parities of theta
+// (10 reads of A) and the rho-pi scatter + chi gather (1 write, 3 reads of B).  A single lane needs ~5000 dependent
+// VALU instructions per permutation (~10 us); this form ~24 x (13 LDS reads + ~40 VALU), measured in DESIGN.md.
+__device__ __forceinline__ void keccak_f1600_wave(uint64_t *A, uint64_t *B, unsigned lane) {
+    const unsigned l = lane % 25u, x = l % 5u, y = l / 5u;
+    const unsigned xm = (x + 4u) % 5u, xp = (x + 1u) % 5u;
+    const unsigned rot = kKeccakRho[l];
+    const unsigned dst = y + 5u * ((2u * x + 3u * y) % 5u);
+    const unsigned i1 = (x + 1u) % 5u + 5u * y, i2 = (x + 2u) % 5u + 5u * y;
+    const uint64_t rc_lane = kKeccakRC[lane < 24u ? lane : 0u];   // round constant r lives in lane r (no memory access per round)
+    uint64_t a = A[l];
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) {
+        if (round) {
+            A[l] = a;
+            wave_lds_sync();
+        }
+        uint64_t cm = A[xm] ^ A[xm + 5] ^ A[xm + 10] ^ A[xm + 15] ^ A[xm + 20];
+        uint64_t cp = A[xp] ^ A[xp + 5] ^ A[xp + 10] ^ A[xp + 15] ^ A[xp + 20];
+        a ^= cm ^ rotl64(cp, 1);                             // theta
+        B[dst] = rotl64(a, rot);                             // rho, pi
+        wave_lds_sync();
+        uint64_t b0 = B[l], b1 = B[i1], b2 = B[i2];
+        a = b0 ^ (~b1 & b2);                                 // chi
+        const uint64_t rc = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rc_lane, round) |
+                            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rc_lane >> 32), round) << 32);
+        a ^= l == 0 ? rc : 0ull;                             // iota
+        wave_lds_sync();                                     // B is rewritten next round: keep the reads above it
+    }
+    A[l] = a;
+    wave_lds_sync();
+}
+
+// One wave, uniform control flow: absorb msg[0 .. nbytes), sample (finalize a clone, append the digest to msg and absorb
+// it back).  The digest words end up in msg[nbytes/4 .. nbytes/4 + 8).  `st` / `cl` / `tmp` are 25-lane LDS states,
+// `fill` the running block fill (uniform).  nbytes is a multiple of 4; `fill` may be anything (the host can have absorbed
+// arbitrary byte strings before): 136 and all message lengths are multiples of 4, so `fill` keeps its alignment
+// for the whole call -- whole words when it is word-aligned, single bytes otherwise.
+__device__ __forceinline__ void sponge_absorb_sample_wave(uint64_t *st, uint64_t *cl, uint64_t *tmp, uint32_t &fill, uint32_t *msg,
+                                                          unsigned nbytes, unsigned lane) {
+    uint8_t *sb = reinterpret_cast<uint8_t *>(st);
+    uint32_t *sw = reinterpret_cast<uint32_t *>(st);
+    const uint8_t *mb = reinterpret_cast<const uint8_t *>(msg);
+    const unsigned total = nbytes + 32;
+    const bool words = (fill & 3u) == 0;
+    unsigned i = 0;
+    bool sampled = false;
+    while (true) {
+        uint64_t *tgt = st;
+        bool perm = false;
+        if (i == nbytes && !sampled) {                       // finalize a clone: pad 0x01 .. 0x80 (Keccak, not SHA-3)
+            if (lane < 25) cl[lane] = st[lane];
+            wave_lds_sync();
+            if (lane == 0) {
+                uint8_t *cb = reinterpret_cast<uint8_t *>(cl);
+                cb[fill] ^= 0x01;
+                cb[135] ^= 0x80;
+            }
+            wave_lds_sync();
+            tgt = cl;
+            perm = true;
+        } else if (i == total) {
+            break;
+        } else {                                             // as much as fits before the block boundary / end of this phase
+            const unsigned end = i < nbytes ? nbytes : total;
+            unsigned n = end - i;
+            if (n > 136u - fill) n = 136u - fill;
+            if (words) {
+                if (lane < (n >> 2)) sw[(fill >> 2) + lane] ^= msg[(i >> 2) + lane];
+            } else {
+                for (unsigned k = lane; k < n; k += 64) sb[fill + k] ^= mb[i + k];
+            }
+            i += n;
+            fill += n;
+            if (fill == 136) { fill = 0; perm = true; }
+            wave_lds_sync();
+        }
+        if (perm) keccak_f1600_wave(tgt, tmp, lane);
+        if (tgt == cl) {                                     // digest = first 32 bytes of the squeezed clone
+            const uint32_t *cw = reinterpret_cast<const uint32_t *>(cl);
+            if (lane < 8) msg[(nbytes >> 2) + lane] = cw[lane];
+            wave_lds_sync();
+            sampled = true;
+        }
+    }
+}
+
+// F::from_le_bytes_mod_order(digest) in Montgomery form: the 256-bit little-endian value V times R^2 through one
+// Montgomery product.  V < R = 2^(32 N) is all the product needs of its left operand (V R^2 / R + p < 2 p before the
+// conditional subtraction), so the result is the canonical V R mod p without reducing V first.
+template <class F> __device__ __forceinline__ Fe<F> challenge_from_digest(const uint32_t *digest_words) {
+    Fe<F> v;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) v.l[i] = i < 8 ? digest_words[i] : 0u;
+    return fe_from_canonical<F>(v);
+}
+
+struct FinishArgs {
+    const void *partials;    // [t * count + block], t < npts
+    size_t count;
+    int npts;                // evaluations per round (2 = basic sumcheck halves, d + 1 for the GKR sumcheck)
+    int mode;                // 0: message = the evaluations, big-endian (prover.rs:50-55)
+                             // 1: message = Lagrange coefficients over 0..d, little-endian (sumcheck_gkr_protocol.rs:46-52)
+    int with_claim;          // mode 0, round 0: absorb evals[0] + evals[1] first (prover.rs:28,40-41)
+    DevSponge *sponge;
+    const void *basis;       // mode 1: basis[i * npts + d] = coefficient d of l_i (Montgomery form), followed by the same
+                             // npts^2 coefficients as canonical integers (ev * canonical = canonical product)
+    void *proof;             // Fe slots
+    size_t claim_slot, msg_slot, chal_slot;
+};
+
+constexpr int kMaxPts = kMaxFactors + 1;
+
+// One workgroup (64..1024 lanes, a multiple of 64).  Stage 1: every wave reduces its share of the partials, all npts
+// sums interleaved (independent shuffle chains).  Everything after the single __syncthreads runs in wave 0: the
+// cross-wave sums (16-lane groups), the round message, the transcript step and the challenge.
+template <class F>
+__global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArgs a) {
+    __shared__ Wide<F> sh[kMaxPts * 16];                     // [t * 16 + wave]
+    __shared__ Fe<F> ev[kMaxPts];
+    __shared__ Fe<F> pr[2 * kMaxPts * kMaxPts];
+    __shared__ uint32_t msg[(kMaxPts + 1) * F::N + 8];
+    __shared__ uint64_t st[25], cl[25], tmp[25];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int npts = a.npts;
+    TS(0);
+    Wide<F> acc[kMaxPts];                                    // lazy sums (mle_kernels.cuh); unused ones stay zero
+#pragma unroll
+    for (int t = 0; t < kMaxPts; t++) {
+        acc[t] = wide_zero<F>();
+        if (t < npts)
+            for (size_t i = tid; i < a.count; i += blockDim.x) wide_add_fe<F>(acc[t], fe_load<F>(a.partials, (size_t)t * a.count + i));
+    }
+    wave_reduce_wide<F, kMaxPts>(acc, npts);
+    if (lane == 63) {
+#pragma unroll
+        for (int t = 0; t < kMaxPts; t++) sh[t * 16 + wave] = acc[t];
+    }
+    if (tid < 25) st[tid] = a.sponge->a[tid];
+    __syncthreads();
+    if (wave != 0) return;
+    {   // cross-wave sums: lane t * 16 + w holds wave w's sum of evaluation t
+        const unsigned t = lane >> 4, w = lane & 15u;
+        Wide<F> v = w < nwaves ? sh[lane] : wide_zero<F>();
+        row_reduce_wide<F>(v);                               // a 16-lane group is one DPP row: sum in its lane 15
+        if (w == 15 && (int)t < npts) ev[t] = wide_reduce<F>(v);
+        wave_lds_sync();
+    }
+    TS(1);
+    const int nmsg = npts + (a.with_claim ? 1 : 0);
+    if (a.mode == 0) {
+        if ((int)lane < nmsg) {
+            const int t = (int)lane;
+            Fe<F> m;
+            size_t slot;
+            if (a.with_claim && t == 0) { m = fe_add<F>(ev[0], ev[1]); slot = a.claim_slot; }
+            else { int k = t - (a.with_claim ? 1 : 0); m = ev[k]; slot = a.msg_slot + k; }
+            fe_store<F>(a.proof, slot, m);
+            Fe<F> c = fe_to_canonical<F>(m);
+#pragma unroll
+            for (int k = 0; k < F::N; k++) msg[t * F::N + k] = __builtin_bswap32(c.l[F::N - 1 - k]);
+        }
+    } else {
+        // coefficient d = sum_i ev[i] * basis[i][d]: the npts^2 products in the stored form and the npts^2 canonical ones
+        // (for the bytes) are taken by 2 npts^2 lanes at once, then npts + npts lanes add them up
+        const int n2 = npts * npts;
+        if ((int)lane < 2 * n2) pr[lane] = fe_mul<F>(ev[((int)lane % n2) / npts], fe_load<F>(a.basis, lane));
+        wave_lds_sync();
+        if ((int)lane < 2 * npts) {
+            const int which = (int)lane / npts, d = (int)lane % npts;
+            Fe<F> m = pr[which * n2 + d];
+#pragma unroll 1
+            for (int i = 1; i < npts; i++) m = fe_add<F>(m, pr[which * n2 + i * npts + d]);
+            if (which == 0) fe_store<F>(a.proof, a.msg_slot + d, m);
+            else {
+#pragma unroll
+                for (int k = 0; k < F::N; k++) msg[d * F::N + k] = m.l[k];
+            }
+        }
+    }
+    wave_lds_sync();
+    TS(2);
+    uint32_t fill = a.sponge->fill;
+    const unsigned nbytes = (unsigned)nmsg * 4u * F::N;
+    sponge_absorb_sample_wave(st, cl, tmp, fill, msg, nbytes, lane);
+    TS(3);
+    if (lane < 25) a.sponge->a[lane] = st[lane];
+    if (lane == 0) {
+        a.sponge->fill = fill;
+        fe_store<F>(a.proof, a.chal_slot, challenge_from_digest<F>(msg + (nbytes >> 2)));
+    }
+    TS(4);
+}
+
+// element 0 of each table -> proof slots (the fully folded values after the last round)
+template <class F> __global__ void gather_first_kernel(SumPolyTables tabs, int ntab, void *proof, size_t slot) {
+    int k = threadIdx.x;
+    if (k < ntab) fe_store<F>(proof, slot + k, fe_load<F>(tabs.in[k], 0));
+}
+
+}  // namespace zk

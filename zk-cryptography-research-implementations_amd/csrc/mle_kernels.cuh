@@ -53,14 +53,20 @@ template <class F> struct Multiplier {
     __device__ __forceinline__ Fe<F> times(const Fe<F> &x) const { return fe_mul_u_pre<F>(u, x); }
 };
 
+// A challenge is passed by value (host-driven callers) or read from device memory (`rp`, written by the previous
+// round's finish kernel: dev_transcript.cuh) -- a uniform 32-byte load.
+template <class F> __device__ __forceinline__ Fe<F> challenge_arg(const Fe<F> &r, const void *rp) {
+    return rp ? fe_load<F>(rp, 0) : r;
+}
+
 // ---- fold: out[i] = y1 + r * (y2 - y1)   evaluation_form.rs:88-89 -----------------------------------
 // `power` = n - 1 - var (:80).  Output index i maps to y1 index j = i with a zero bit inserted
 // at position `power` (the reference's j-walk :98-102), y2 = j | 1<<power (:82).
 template <class F> __global__ void fold_kernel(const void *__restrict__ in, void *__restrict__ out,
-                                              size_t half, unsigned power, Fe<F> r) {
+                                              size_t half, unsigned power, Fe<F> r, const void *__restrict__ rp = nullptr) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t lowmask = ((size_t)1 << power) - 1;
-    const Multiplier<F> mr(r);
+    const Multiplier<F> mr(challenge_arg<F>(r, rp));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
         size_t j = ((i & ~lowmask) << 1) | (i & lowmask);
         Fe<F> y1 = fe_load<F>(in, j);
@@ -80,55 +86,116 @@ template <class F> __global__ void fold0_kernel(const void *__restrict__ in, voi
 }
 
 // ---- reductions ------------------------------------------------------------------------------------
-template <class F> __device__ __forceinline__ Fe<F> wave_reduce_add(Fe<F> v) {
+// Sums are accumulated LAZILY: a Wide is the plain integer sum (N + 1 limbs: up to 2^32 terms below 2^(32 N)), one
+// carry chain per addition (N + 1 VALU ops instead of ~35 for a modular addition with its conditional subtraction),
+// and is reduced mod p once per workgroup.  The result is the same fully reduced element (sum of the stored forms =
+// stored form of the sum).
+template <class F> struct Wide {
+    uint32_t l[F::N + 1];
+};
+template <class F> __device__ __forceinline__ Wide<F> wide_zero() {
+    Wide<F> w;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        Fe<F> o;
-#pragma unroll
-        for (int k = 0; k < F::N; k++) o.l[k] = __shfl_down(v.l[k], off, 64);
-        v = fe_add<F>(v, o);
-    }
-    return v;
+    for (int i = 0; i <= F::N; i++) w.l[i] = 0;
+    return w;
 }
-// block-wide sum; valid in thread 0.  `sh` holds kBlock/64 elements.
-template <class F> __device__ __forceinline__ Fe<F> block_reduce_add(Fe<F> v, Fe<F> *sh) {
-    v = wave_reduce_add<F>(v);
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    Fe<F> tot = fe_zero<F>();
-    if (threadIdx.x == 0) {
-        tot = sh[0];
-        for (int w = 1; w < (int)(blockDim.x >> 6); w++) tot = fe_add<F>(tot, sh[w]);
+template <class F> __device__ __forceinline__ void wide_add_fe(Wide<F> &w, const Fe<F> &a) {
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) w.l[i] = __builtin_addc(w.l[i], a.l[i], c, &c);
+    w.l[F::N] += c;
+}
+template <class F> __device__ __forceinline__ void wide_add(Wide<F> &w, const Wide<F> &o) {
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i <= F::N; i++) w.l[i] = __builtin_addc(w.l[i], o.l[i], c, &c);
+}
+// S mod p.  Split S = lo + hi 2^s at s = bitlen(p) - 1, so lo < 2^s < p is already canonical and hi < 2^34 or so;
+// hi 2^s mod p = mont(mont(hi, R^2), 2^s) -- two products, taken once per workgroup.
+template <class F> __device__ __forceinline__ Fe<F> wide_reduce(const Wide<F> &w) {
+    constexpr int N = F::N;
+    const int tb = 31 - __builtin_clz(F::p(N - 1));       // bit s within the top limb (1..31 for all four moduli)
+    Fe<F> lo, hi = fe_zero<F>(), pw = fe_zero<F>();
+#pragma unroll
+    for (int i = 0; i < N; i++) lo.l[i] = w.l[i];
+    lo.l[N - 1] &= (1u << tb) - 1u;
+    hi.l[0] = (w.l[N - 1] >> tb) | (w.l[N] << (32 - tb));
+    hi.l[1] = w.l[N] >> tb;
+    pw.l[N - 1] = 1u << tb;
+    return fe_add<F>(lo, fe_mul<F>(fe_from_canonical<F>(hi), pw));
+}
+// Cross-lane steps use DPP (VALU rate; __shfl_down would be a ds_bpermute per limb and makes a many-wave reduction
+// LDS-crossbar bound).  Lanes without a source add zero.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <class F, int CTRL, int ROW_MASK> __device__ __forceinline__ void wide_dpp_step(Wide<F> &v) {
+    Wide<F> o;
+#pragma unroll
+    for (int k = 0; k <= F::N; k++) o.l[k] = dpp_or_zero<CTRL, ROW_MASK>(v.l[k]);
+    wide_add<F>(v, o);
+}
+// sum over each row of 16 lanes, valid in the row's lane 15 (row_shr:1,2,4,8)
+template <class F> __device__ __forceinline__ void row_reduce_wide(Wide<F> &v) {
+    wide_dpp_step<F, 0x111, 0xf>(v);
+    wide_dpp_step<F, 0x112, 0xf>(v);
+    wide_dpp_step<F, 0x114, 0xf>(v);
+    wide_dpp_step<F, 0x118, 0xf>(v);
+}
+// sum over the wave, valid in lane 63 (then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).
+// The first `active` of K independent sums are reduced (uniform), their instruction streams interleave.
+template <class F, int K> __device__ __forceinline__ void wave_reduce_wide(Wide<F> (&v)[K], int active = K) {
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        if (k < active) {
+            row_reduce_wide<F>(v[k]);
+            wide_dpp_step<F, 0x142, 0xa>(v[k]);
+            wide_dpp_step<F, 0x143, 0xc>(v[k]);
+        }
+}
+// Workgroup sums of K lazily accumulated values.  `sh` holds K * (blockDim.x / 64) Wides.  Returns true in the K lanes
+// (threads 0..K-1) that hold a result: thread k gets sum k, fully reduced.  Contains one __syncthreads; callers that
+// reuse `sh` afterwards must synchronise again.
+template <class F, int K> __device__ __forceinline__ bool block_reduce_wide(Wide<F> (&v)[K], Wide<F> *sh, Fe<F> &out) {
+    wave_reduce_wide<F, K>(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < K; k++) sh[k * nw + wave] = v[k];
     }
     __syncthreads();
-    return tot;
+    if ((int)threadIdx.x >= K) return false;
+    Wide<F> tot = sh[threadIdx.x * nw];
+    for (int w = 1; w < nw; w++) wide_add<F>(tot, sh[threadIdx.x * nw + w]);
+    out = wide_reduce<F>(tot);
+    return true;
 }
 
 // partial sums of `nseg` equal contiguous segments of the table: partials[seg * gridDim.x + block]
 // (nseg = 1: iter().sum() prover.rs:28 ; nseg = 2: split_polynomial_and_sum_each prover.rs:74-89)
 template <class F> __global__ void segment_sums_kernel(const void *__restrict__ in, size_t seglen, int nseg,
                                                       void *__restrict__ partials) {
-    __shared__ Fe<F> sh[kBlock / 64];
+    __shared__ Wide<F> sh[kBlock / 64];
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (int s = 0; s < nseg; s++) {
-        Fe<F> acc = fe_zero<F>();
+        Wide<F> acc[1] = {wide_zero<F>()};
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < seglen; i += stride)
-            acc = fe_add<F>(acc, fe_load<F>(in, (size_t)s * seglen + i));
-        Fe<F> tot = block_reduce_add<F>(acc, sh);
-        if (threadIdx.x == 0) fe_store<F>(partials, (size_t)s * gridDim.x + blockIdx.x, tot);
+            wide_add_fe<F>(acc[0], fe_load<F>(in, (size_t)s * seglen + i));
+        Fe<F> tot;
+        if (block_reduce_wide<F, 1>(acc, sh, tot)) fe_store<F>(partials, (size_t)s * gridDim.x + blockIdx.x, tot);
+        __syncthreads();
     }
 }
 // one block: out[s] = sum of partials[s * count .. (s+1) * count)
 template <class F> __global__ void finish_sums_kernel(const void *__restrict__ partials, size_t count, int nseg,
                                                      void *__restrict__ out) {
-    __shared__ Fe<F> sh[kBlock / 64];
+    __shared__ Wide<F> sh[kBlock / 64];
     for (int s = 0; s < nseg; s++) {
-        Fe<F> acc = fe_zero<F>();
-        for (size_t i = threadIdx.x; i < count; i += blockDim.x)
-            acc = fe_add<F>(acc, fe_load<F>(partials, (size_t)s * count + i));
-        Fe<F> tot = block_reduce_add<F>(acc, sh);
-        if (threadIdx.x == 0) fe_store<F>(out, s, tot);
+        Wide<F> acc[1] = {wide_zero<F>()};
+        for (size_t i = threadIdx.x; i < count; i += blockDim.x) wide_add_fe<F>(acc[0], fe_load<F>(partials, (size_t)s * count + i));
+        Fe<F> tot;
+        if (block_reduce_wide<F, 1>(acc, sh, tot)) fe_store<F>(out, s, tot);
+        __syncthreads();
     }
 }
 
@@ -136,11 +203,12 @@ template <class F> __global__ void finish_sums_kernel(const void *__restrict__ p
 // (prover.rs:50 of round k+1 fused into prover.rs:61-63 of round k.)  in has 4q elements,
 // out has 2q; lane handles output indices i and i + q: 4 loads, 2 stores, 2 multiplications.
 template <class F> __global__ void fold_half_sums_kernel(const void *__restrict__ in, void *__restrict__ out,
-                                                        size_t q, Fe<F> r, void *__restrict__ partials) {
-    __shared__ Fe<F> sh[kBlock / 64];
+                                                        size_t q, Fe<F> r, void *__restrict__ partials,
+                                                        const void *__restrict__ rp = nullptr) {
+    __shared__ Wide<F> sh[2 * kBlock / 64];
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    Fe<F> s0 = fe_zero<F>(), s1 = fe_zero<F>();
-    const Multiplier<F> mr(r);
+    Wide<F> sum[2] = {wide_zero<F>(), wide_zero<F>()};
+    const Multiplier<F> mr(challenge_arg<F>(r, rp));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
         Fe<F> a0 = fe_load<F>(in, i), a1 = fe_load<F>(in, i + q);
         Fe<F> b0 = fe_load<F>(in, i + 2 * q), b1 = fe_load<F>(in, i + 3 * q);
@@ -148,15 +216,11 @@ template <class F> __global__ void fold_half_sums_kernel(const void *__restrict_
         Fe<F> o1 = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
         fe_store<F>(out, i, o0);
         fe_store<F>(out, i + q, o1);
-        s0 = fe_add<F>(s0, o0);
-        s1 = fe_add<F>(s1, o1);
+        wide_add_fe<F>(sum[0], o0);
+        wide_add_fe<F>(sum[1], o1);
     }
-    Fe<F> t0 = block_reduce_add<F>(s0, sh);
-    Fe<F> t1 = block_reduce_add<F>(s1, sh);
-    if (threadIdx.x == 0) {
-        fe_store<F>(partials, blockIdx.x, t0);
-        fe_store<F>(partials, (size_t)gridDim.x + blockIdx.x, t1);
-    }
+    Fe<F> tot;
+    if (block_reduce_wide<F, 2>(sum, sh, tot)) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
 }
 
 // ---- element-wise and tensor operations --------------------------------------------------------------

@@ -27,7 +27,7 @@ struct SumPolyTables {
 
 // accumulate the NFAC+1 evaluation terms of one product at one pair index
 template <class F, int NFAC>
-__device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const Fe<F> (&hi)[NFAC], Fe<F> (&acc)[NFAC + 1]) {
+__device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const Fe<F> (&hi)[NFAC], Wide<F> (&acc)[NFAC + 1]) {
     Fe<F> v[NFAC], d[NFAC];
 #pragma unroll
     for (int f = 0; f < NFAC; f++) {
@@ -39,7 +39,7 @@ __device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const 
         Fe<F> term = v[0];
 #pragma unroll
         for (int f = 1; f < NFAC; f++) term = fe_mul<F>(term, v[f]);
-        acc[t] = fe_add<F>(acc[t], term);
+        wide_add_fe<F>(acc[t], term);
         if (t < NFAC) {
 #pragma unroll
             for (int f = 0; f < NFAC; f++) v[f] = fe_add<F>(v[f], d[f]);   // X_{t+1} = X_t + (hi - lo)
@@ -48,21 +48,18 @@ __device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const 
 }
 
 template <class F, int NFAC>
-__device__ __forceinline__ void write_partials(Fe<F> (&acc)[NFAC + 1], Fe<F> *sh, void *partials) {
-#pragma unroll
-    for (int t = 0; t <= NFAC; t++) {
-        Fe<F> tot = block_reduce_add<F>(acc[t], sh);
-        if (threadIdx.x == 0) fe_store<F>(partials, (size_t)t * gridDim.x + blockIdx.x, tot);
-    }
+__device__ __forceinline__ void write_partials(Wide<F> (&acc)[NFAC + 1], Wide<F> *sh, void *partials) {
+    Fe<F> tot;
+    if (block_reduce_wide<F, NFAC + 1>(acc, sh, tot)) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
 }
 
 // tables of `2 * half` entries; partials[t * gridDim.x + block]
 template <class F, int NFAC>
 __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials) {
-    __shared__ Fe<F> sh[kBlock / 64];
-    Fe<F> acc[NFAC + 1];
+    __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];
+    Wide<F> acc[NFAC + 1];
 #pragma unroll
-    for (int t = 0; t <= NFAC; t++) acc[t] = fe_zero<F>();
+    for (int t = 0; t <= NFAC; t++) acc[t] = wide_zero<F>();
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
         for (int p = 0; p < nprod; p++) {
@@ -81,13 +78,14 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
 // tables of 4q entries in, 2q out; lane i folds outputs i and i+q of every table, then uses them
 // as the (lo, hi) pair of the NEXT round.
 template <class F, int NFAC>
-__global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials) {
-    __shared__ Fe<F> sh[kBlock / 64];
-    Fe<F> acc[NFAC + 1];
+__global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials,
+                                                                  const void *__restrict__ rp = nullptr) {
+    __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];
+    Wide<F> acc[NFAC + 1];
 #pragma unroll
-    for (int t = 0; t <= NFAC; t++) acc[t] = fe_zero<F>();
+    for (int t = 0; t <= NFAC; t++) acc[t] = wide_zero<F>();
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    const Multiplier<F> mr(r);
+    const Multiplier<F> mr(challenge_arg<F>(r, rp));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
         for (int p = 0; p < nprod; p++) {
             Fe<F> lo[NFAC], hi[NFAC];
@@ -110,9 +108,9 @@ __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables 
 
 // plain fold of every table (used for the last round, 2-entry tables)
 template <class F>
-__global__ void fold_all_kernel(SumPolyTables tabs, int ntab, size_t half, Fe<F> r) {
+__global__ void fold_all_kernel(SumPolyTables tabs, int ntab, size_t half, Fe<F> r, const void *__restrict__ rp = nullptr) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    const Multiplier<F> mr(r);
+    const Multiplier<F> mr(challenge_arg<F>(r, rp));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride)
         for (int k = 0; k < ntab; k++) {
             Fe<F> y1 = fe_load<F>(tabs.in[k], i), y2 = fe_load<F>(tabs.in[k], i + half);

@@ -49,6 +49,10 @@ class Keccak256 {
         for (int i = 0; i < 32; i++) out[i] = (uint8_t)(c.a_[i / 8] >> (8 * (i % 8)));
     }
 
+    // the sponge moves between host and device (dev_transcript.cuh): 25 lanes + bytes in the open block
+    void export_state(uint64_t a[25], uint32_t *fill) const { memcpy(a, a_, sizeof a_); *fill = (uint32_t)fill_; }
+    void import_state(const uint64_t a[25], uint32_t fill) { memcpy(a_, a, sizeof a_); fill_ = fill; }
+
   private:
     static constexpr size_t kRate = 136;
     uint64_t a_[25];
@@ -109,6 +113,8 @@ class Transcript {
         host_to_bytes_le<F>(x, b);
         append(b, sizeof b);
     }
+
+    Keccak256 &sponge() { return h_; }
 
   private:
     Keccak256 h_;

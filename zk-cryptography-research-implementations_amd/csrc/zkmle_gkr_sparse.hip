@@ -123,19 +123,15 @@ template <class F> __global__ void circuit_layer_kernel(GateArrays g, const uint
 }
 // partial sums over gates of w_g eqL[left] eqR[right] split by gate type (verifier-side check)
 template <class F> __global__ void wiring_eval_kernel(GateArrays g, size_t n, const void *w, const void *eqL, const void *eqR, void *partials) {
-    __shared__ Fe<F> sh[kBlock / 64];
-    Fe<F> a = fe_zero<F>(), m = fe_zero<F>();
+    __shared__ Wide<F> sh[2 * kBlock / 64];
+    Wide<F> am[2] = {wide_zero<F>(), wide_zero<F>()};            // [0] add gates, [1] mul gates
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         Fe<F> t = fe_mul<F>(fe_mul<F>(fe_load<F>(w, i), fe_load<F>(eqL, g.left[i])), fe_load<F>(eqR, g.right[i]));
-        if (g.op[i] == 0) a = fe_add<F>(a, t); else m = fe_add<F>(m, t);
+        if (g.op[i] == 0) wide_add_fe<F>(am[0], t); else wide_add_fe<F>(am[1], t);
     }
-    Fe<F> ta = block_reduce_add<F>(a, sh);
-    Fe<F> tm = block_reduce_add<F>(m, sh);
-    if (threadIdx.x == 0) {
-        fe_store<F>(partials, blockIdx.x, ta);
-        fe_store<F>(partials, (size_t)gridDim.x + blockIdx.x, tm);
-    }
+    Fe<F> tot;
+    if (block_reduce_wide<F, 2>(am, sh, tot)) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
 }
 
 // ---- host-side circuit structure ------------------------------------------------------------------------------

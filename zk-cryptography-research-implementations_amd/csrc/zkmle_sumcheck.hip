@@ -3,9 +3,11 @@
 // control path (Keccak transcript, 3-point interpolation).
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "context.h"
+#include "dev_transcript.cuh"
 #include "sumcheck_kernels.cuh"
 #include "transcript.h"
 #include "univariate.h"
@@ -20,6 +22,10 @@ template <class F> Fe<F> load_el(const uint64_t *src) {
     return e;
 }
 template <class F> void store_el(uint64_t *dst, const Fe<F> &e) { memcpy(dst, e.l, 4 * F::N); }
+
+// host-clock split of the last prover call on this thread (zk_sumcheck_last_stats)
+thread_local zk_sumcheck_stats g_stats{};
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct DevBuf {   // RAII device allocation
     void *p = nullptr;
@@ -51,13 +57,70 @@ template <class F> int download_elems(const void *d, size_t n, Fe<F> *out) {
     return ZK_OK;
 }
 
+// Device-resident rounds (dev_transcript.cuh): one pooled block holds the sponge, the interpolation basis and the proof
+// slots; it is uploaded once before the first round and downloaded once after the last.
+template <class F> struct DeviceRounds {
+    static constexpr size_t kHead = 256;               // DevSponge, padded
+    DevBuf buf;
+    size_t nbasis = 0, nslots = 0;
+    std::vector<uint8_t> host;
+    char *base() const { return (char *)buf.p; }
+    DevSponge *sponge() const { return (DevSponge *)buf.p; }
+    void *basis() const { return base() + kHead; }
+    void *proof() const { return base() + kHead + nbasis * 4 * F::N; }
+    void *slot_ptr(size_t s) const { return (char *)proof() + s * 4 * F::N; }
+    size_t bytes() const { return kHead + (nbasis + nslots) * 4 * F::N; }
+    int init(Transcript &tr, const std::vector<Fe<F>> &basis_flat, size_t slots) {
+        static_assert(sizeof(DevSponge) <= kHead, "sponge header");
+        nbasis = basis_flat.size();
+        nslots = slots;
+        ZK_TRY(buf.alloc(bytes()));
+        host.assign(kHead + nbasis * 4 * F::N, 0);
+        DevSponge sp{};
+        tr.sponge().export_state(sp.a, &sp.fill);
+        memcpy(host.data(), &sp, sizeof sp);
+        if (nbasis) memcpy(host.data() + kHead, basis_flat.data(), nbasis * 4 * F::N);
+        ZK_HIP(hipMemcpy(buf.p, host.data(), host.size(), hipMemcpyHostToDevice));
+        return ZK_OK;
+    }
+    int launch_finish(const void *partials, size_t count, int npts, int mode, int with_claim, size_t claim_slot, size_t msg_slot,
+                      size_t chal_slot) {
+        FinishArgs a{};
+        a.partials = partials; a.count = count; a.npts = npts; a.mode = mode; a.with_claim = with_claim;
+        a.sponge = sponge(); a.basis = basis(); a.proof = proof();
+        a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
+        size_t threads = (count + 63) / 64 * 64;          // one partial per lane up to 1024 lanes
+        if (threads > (size_t)kFinishBlock) threads = kFinishBlock;
+        sumcheck_finish_kernel<F><<<1, (int)threads>>>(a);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    // the single synchronisation of the sumcheck: proof slots + sponge back to the host
+    int collect(Transcript &tr) {
+        host.resize(bytes());
+        ZK_HIP(hipMemcpy(host.data(), buf.p, bytes(), hipMemcpyDeviceToHost));
+        DevSponge sp;
+        memcpy(&sp, host.data(), sizeof sp);
+        tr.sponge().import_state(sp.a, sp.fill);
+        return ZK_OK;
+    }
+    Fe<F> slot(size_t s) const {
+        Fe<F> e;
+        memcpy(e.l, host.data() + kHead + (nbasis + s) * 4 * F::N, 4 * F::N);
+        return e;
+    }
+};
+
 // ---- basic sumcheck prover: prover.rs:22-71 ----------------------------------------------------------
 template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys, uint64_t *challenges) {
     const size_t esz = 4 * F::N, L64 = F::N / 2;
     size_t len = table->len;
     unsigned nvars = ilog2(len);
     Transcript tr;
+    double t0 = now_ms();
     ZK_TRY(absorb_table<F>(tr, table->dptr, len));                     // :38-39
+    double t1 = now_ms();
+    g_stats = zk_sumcheck_stats{nvars, (float)(t1 - t0), 0.f};
     // working buffers: len/2 and len/4 elements, plus reduction partials
     DevBuf bufA, bufB;
     ZK_TRY(bufA.alloc((len / 2) * esz));
@@ -71,39 +134,30 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
         tr.append_be<F>(sums[0]);
         return ZK_OK;
     }
-    // round-0 half sums (split_polynomial_and_sum_each :74-89); claimed sum = their sum (:28)
-    {
+    // Proof slots: 0 = claimed sum; round k: 1+3k, 2+3k = the two half sums, 3+3k = the challenge.
+    // Every transcript step from here on runs on the device (dev_transcript.cuh): no host round trip per round.
+    DeviceRounds<F> dr;
+    ZK_TRY(dr.init(tr, std::vector<Fe<F>>(), 1 + 3 * (size_t)nvars));
+    {   // round-0 half sums (split_polynomial_and_sum_each :74-89); claimed sum = their sum (:28), absorbed first (:40-41)
         size_t seg = len / 2;
         int grid = reduce_grid_for(seg);
-        void *res = (char *)part + esz * (size_t)grid * 2;
         segment_sums_kernel<F><<<grid, kBlock>>>(table->dptr, seg, 2, part);
-        finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, 2, res);
         ZK_HIP(hipGetLastError());
-        ZK_TRY(download_elems<F>(res, 2, sums));
+        ZK_TRY(dr.launch_finish(part, (size_t)grid, 2, 0, 1, 0, 1, 3));               // :50-58 of round 0
     }
-    Fe<F> claimed = fe_add<F>(sums[0], sums[1]);
-    store_el<F>(claimed_sum, claimed);
-    tr.append_be<F>(claimed);                                          // :40-41
     const void *cur = table->dptr;
     void *dst = bufA.p, *other = bufB.p;
     size_t cl = len;
     for (unsigned round = 0; round < nvars; round++) {                 // :46
-        store_el<F>(round_polys + (size_t)(2 * round) * L64, sums[0]); // :50-53
-        store_el<F>(round_polys + (size_t)(2 * round + 1) * L64, sums[1]);
-        tr.append_be<F>(sums[0]);                                      // :54-55 (a 2-entry table, big-endian)
-        tr.append_be<F>(sums[1]);
-        Fe<F> r = tr.random_challenge_as_field_element<F>();           // :58
-        if (challenges) store_el<F>(challenges + (size_t)round * L64, r);
+        const void *rp = dr.slot_ptr(3 + 3 * (size_t)round);           // this round's challenge (:58), on the device
         if (cl >= 4) {                                                 // :61-63 fused with the next round's :50
             size_t q = cl / 4;
             int grid = reduce_grid_for(q);
-            void *res = (char *)part + esz * (size_t)grid * 2;
-            fold_half_sums_kernel<F><<<grid, kBlock>>>(cur, dst, q, r, part);
-            finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, 2, res);
+            fold_half_sums_kernel<F><<<grid, kBlock>>>(cur, dst, q, fe_zero<F>(), part, rp);
             ZK_HIP(hipGetLastError());
-            ZK_TRY(download_elems<F>(res, 2, sums));
+            ZK_TRY(dr.launch_finish(part, (size_t)grid, 2, 0, 0, 0, 1 + 3 * (size_t)(round + 1), 3 + 3 * (size_t)(round + 1)));
         } else {                                                       // 2 entries -> 1: nothing left to sum
-            fold_kernel<F><<<1, kBlock>>>(cur, dst, 1, 0, r);
+            fold_kernel<F><<<1, kBlock>>>(cur, dst, 1, 0, fe_zero<F>(), rp);
             ZK_HIP(hipGetLastError());
         }
         cur = dst;
@@ -112,7 +166,14 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
         dst = nx;
         cl /= 2;
     }
-    ZK_HIP(hipDeviceSynchronize());
+    ZK_TRY(dr.collect(tr));
+    g_stats.ms_rounds = (float)(now_ms() - t1);
+    store_el<F>(claimed_sum, dr.slot(0));
+    for (unsigned round = 0; round < nvars; round++) {
+        store_el<F>(round_polys + (size_t)(2 * round) * L64, dr.slot(1 + 3 * (size_t)round));
+        store_el<F>(round_polys + (size_t)(2 * round + 1) * L64, dr.slot(2 + 3 * (size_t)round));
+        if (challenges) store_el<F>(challenges + (size_t)round * L64, dr.slot(3 + 3 * (size_t)round));
+    }
     return ZK_OK;
 }
 
@@ -163,10 +224,11 @@ template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, 
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
-template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t q, const Fe<F> &r, void *part, int grid) {
-    if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock>>>(tabs, nprod, q, r, part);
-    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock>>>(tabs, nprod, q, r, part);
-    else fold_round_evals_kernel<F, 3><<<grid, kBlock>>>(tabs, nprod, q, r, part);
+template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t q, const Fe<F> &r, void *part, int grid,
+                                               const void *rp = nullptr) {
+    if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock>>>(tabs, nprod, q, r, part, rp);
+    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock>>>(tabs, nprod, q, r, part, rp);
+    else fold_round_evals_kernel<F, 3><<<grid, kBlock>>>(tabs, nprod, q, r, part, rp);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -207,43 +269,42 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
     ZK_TRY(bufB.alloc(ntab * (len / 4) * esz));
     void *part;
     ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
-    std::vector<Fe<F>> xs(npts), evals(npts);
+    std::vector<Fe<F>> xs(npts);
     for (size_t i = 0; i < npts; i++) xs[i] = fe_from_u64<F>(i);       // :46-48
     const std::vector<std::vector<Fe<F>>> basis = lagrange_basis_matrix<F>(xs);   // nodes 0..d never change
+    std::vector<Fe<F>> basis_flat(2 * npts * npts);        // Montgomery form, then the canonical integers (FinishArgs::basis)
+    for (size_t i = 0; i < npts; i++)
+        for (size_t d = 0; d < npts; d++) {
+            basis_flat[i * npts + d] = basis[i][d];
+            basis_flat[npts * npts + i * npts + d] = fe_to_canonical<F>(basis[i][d]);
+        }
+    // Proof slots: round k: (npts+1)k .. +npts-1 = coefficients (:49-52), +npts = challenge (:55); then ntab final values.
+    // Interpolation, absorb and challenge of every round run in the finish kernel (dev_transcript.cuh).
+    const size_t per = npts + 1, fin_slot = per * nvars;
+    const double t1 = now_ms();
+    DeviceRounds<F> dr;
+    ZK_TRY(dr.init(tr, basis_flat, fin_slot + ntab));
     SumPolyTables tabs{};
     for (size_t k = 0; k < ntab; k++) tabs.in[k] = tables[k]->dptr;
-    // round 0 evaluations
-    {
+    {   // round 0 evaluations
         size_t half = len / 2;
         int grid = reduce_grid_for(half);
-        void *res = (char *)part + esz * (size_t)grid * npts;
         ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
-        finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, (int)npts, res);
-        ZK_HIP(hipGetLastError());
-        ZK_TRY(download_elems<F>(res, npts, evals.data()));
+        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, 0, npts));
     }
     char *dst = (char *)bufA.p, *other = (char *)bufB.p;
     size_t cl = len;
     for (unsigned round = 0; round < nvars; round++) {                 // :37
-        std::vector<Fe<F>> co = interpolate_with_basis<F>(basis, evals);   // :49-50 (same coefficients, no per-round inversions)
-        for (size_t i = 0; i < npts; i++) {
-            tr.append_le<F>(co[i]);                                    // :52 little-endian coefficients
-            store_el<F>(round_coeffs + ((size_t)round * npts + i) * L64, co[i]);
-        }
-        Fe<F> r = tr.random_challenge_as_field_element<F>();           // :55
-        store_el<F>(challenges + (size_t)round * L64, r);              // :59
+        const void *rp = dr.slot_ptr(per * round + npts);              // :55, on the device
         size_t ol = cl / 2;
         for (size_t k = 0; k < ntab; k++) tabs.out[k] = dst + k * ol * esz;
         if (cl >= 4) {                                                 // :57 fused with next round's :41
             size_t q = cl / 4;
             int grid = reduce_grid_for(q);
-            void *res = (char *)part + esz * (size_t)grid * npts;
-            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, r, part, grid)));
-            finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, (int)npts, res);
-            ZK_HIP(hipGetLastError());
-            ZK_TRY(download_elems<F>(res, npts, evals.data()));
+            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp)));
+            ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, per * (round + 1), per * (round + 1) + npts));
         } else {
-            fold_all_kernel<F><<<1, kBlock>>>(tabs, (int)ntab, 1, r);
+            fold_all_kernel<F><<<1, kBlock>>>(tabs, (int)ntab, 1, fe_zero<F>(), rp);
             ZK_HIP(hipGetLastError());
         }
         for (size_t k = 0; k < ntab; k++) tabs.in[k] = tabs.out[k];
@@ -252,9 +313,16 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
         dst = nx;
         cl = ol;
     }
-    ZK_HIP(hipDeviceSynchronize());
+    gather_first_kernel<F><<<1, 64>>>(tabs, (int)ntab, dr.proof(), fin_slot);
+    ZK_HIP(hipGetLastError());
+    ZK_TRY(dr.collect(tr));
+    g_stats = zk_sumcheck_stats{nvars, 0.f, (float)(now_ms() - t1)};
+    for (unsigned round = 0; round < nvars; round++) {
+        for (size_t i = 0; i < npts; i++) store_el<F>(round_coeffs + ((size_t)round * npts + i) * L64, dr.slot(per * round + i));
+        store_el<F>(challenges + (size_t)round * L64, dr.slot(per * round + npts));   // :59
+    }
     if (final_values)
-        for (size_t k = 0; k < ntab; k++) ZK_HIP(hipMemcpy(final_values + k * L64, tabs.in[k], esz, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < ntab; k++) store_el<F>(final_values + k * L64, dr.slot(fin_slot + k));
     return ZK_OK;
 }
 
@@ -334,6 +402,12 @@ int zk_uni_lagrange_interpolate(int field, const uint64_t *xs, const uint64_t *y
         std::vector<Fe<F>> c = lagrange_interpolate<F>(x, y);
         for (size_t i = 0; i < n; i++) store_el<F>(out + i * (F::N / 2), c[i]);
     });
+    return ZK_OK;
+}
+
+int zk_sumcheck_last_stats(zk_sumcheck_stats *out) {
+    if (!out) return ZK_E_ARG;
+    *out = g_stats;
     return ZK_OK;
 }
 

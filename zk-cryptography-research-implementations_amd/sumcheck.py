@@ -13,12 +13,17 @@ from . import _lib as L
 from .mle import MultilinearPolynomial, limbs
 
 
+class SumcheckStats(C.Structure):
+    _fields_ = [("rounds", C.c_uint32), ("ms_absorb", C.c_float), ("ms_rounds", C.c_float)]
+
+
 def _decl():
     lib = L.lib()
     if getattr(lib, "_sumcheck_declared", False):
         return lib
     vp, sz, u64p, u8p = L.vp, L.sz, L.u64p, L.u8p
     sigs = {
+        "zk_sumcheck_last_stats": [C.POINTER(SumcheckStats)],
         "zk_transcript_new": [C.POINTER(vp)], "zk_transcript_free": [vp],
         "zk_transcript_append": [vp, u8p, sz], "zk_transcript_sample": [vp, u8p],
         "zk_transcript_challenge": [vp, C.c_int, u64p], "zk_keccak256": [u8p, sz, u8p],
@@ -38,6 +43,13 @@ def _decl():
         fn.restype = C.c_int
     lib._sumcheck_declared = True
     return lib
+
+
+def last_stats():
+    """Host-clock split of the last prover call on this thread: {'rounds', 'ms_absorb', 'ms_rounds'}."""
+    st = SumcheckStats()
+    L.check(_decl().zk_sumcheck_last_stats(C.byref(st)))
+    return {"rounds": st.rounds, "ms_absorb": st.ms_absorb, "ms_rounds": st.ms_rounds}
 
 
 def _bytes_arr(data):
