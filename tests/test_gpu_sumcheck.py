@@ -197,3 +197,29 @@ def test_gkr_sumcheck_large_2p20(zk):
     result = zk.sumcheck.prove(sp, claimed, zk.Transcript())
     co, ch = O.sumcheck_gkr_prove(field, tabs, claimed, O.Transcript())
     assert np.array_equal(result.round_univariate_polynomials, co) and np.array_equal(result.random_challenges, ch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field", [0, 1, 3])
+def test_device_transcript_any_sponge_fill(zk, field):
+    """The rounds run against a sponge that lives on the device (csrc/dev_transcript.cuh).  Whatever the host absorbed
+    before -- any length mod 4 (byte-granular path) and mod 136 (block boundary inside the message, inside the digest,
+    exactly at the end) -- proof, challenges and the sponge handed back must equal the oracle's."""
+    n = 1 << 3
+    tabs = np.stack([np.stack([rand_table(zk, field, n, 900 + 2 * p + f) for f in range(2)]) for p in range(2)])
+    sp = mk_sum(zk, field, tabs)
+    claimed = O.vec_sum(field, O.sumpoly_reduce(field, tabs))
+    for plen in [0, 1, 2, 3, 4, 5, 7, 8, 39, 40, 41, 63, 100, 103, 104, 105, 131, 132, 133, 134, 135, 136, 137, 271, 272, 273]:
+        prefix = bytes((7 * i + plen) & 0xFF for i in range(plen))
+        t_gpu, t_cpu = zk.Transcript(), O.Transcript()
+        t_gpu.append(prefix)
+        t_cpu.append(prefix)
+        result = zk.sumcheck.prove(sp, claimed, t_gpu)
+        co, ch = O.sumcheck_gkr_prove(field, tabs, claimed, t_cpu)
+        assert np.array_equal(result.round_univariate_polynomials, co), plen
+        assert np.array_equal(result.random_challenges, ch), plen
+        t_gpu.append(b"\x01\x02\x03")                     # the host sponge continues from the device state
+        t_cpu.append(b"\x01\x02\x03")
+        assert t_gpu.sample_random_challenge() == t_cpu.sample_random_challenge(), plen
+    st = zk.sumcheck.last_stats()
+    assert st["rounds"] == 3 and st["ms_rounds"] > 0

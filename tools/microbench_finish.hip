@@ -18,8 +18,8 @@ int main(int argc, char **argv) {
     int threads = (int)((count + 63) / 64 * 64); if (threads > kFinishBlock) threads = kFinishBlock;
     hipMalloc(&buf, 4096); hipMemset(buf, 0, 4096);
     FinishArgs a{};
-    a.partials = part; a.count = count; a.npts = npts; a.mode = 1; a.with_claim = 0;
-    a.sponge = (DevSponge *)buf; a.basis = (char *)buf + 256; a.proof = (char *)buf + 1024; a.msg_slot = 0; a.chal_slot = 3;
+    a.partials = part; a.count = count; a.ctx.npts = npts; a.ctx.mode = 1; a.with_claim = 0;
+    a.ctx.sponge = (DevSponge *)buf; a.ctx.basis = (char *)buf + 256; a.ctx.proof = (char *)buf + 1024; a.msg_slot = 0; a.chal_slot = 3;
     for (int it = 0; it < 5; it++) {
         sumcheck_finish_kernel<F><<<1, threads>>>(a);
         hipDeviceSynchronize();

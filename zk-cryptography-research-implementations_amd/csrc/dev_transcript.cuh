@@ -146,34 +146,94 @@ template <class F> __device__ __forceinline__ Fe<F> challenge_from_digest(const 
     return fe_from_canonical<F>(v);
 }
 
-struct FinishArgs {
-    const void *partials;    // [t * count + block], t < npts
-    size_t count;
+constexpr int kMaxPts = kMaxFactors + 1;
+
+// what a round's transcript step needs besides the evaluations
+struct RoundCtx {
     int npts;                // evaluations per round (2 = basic sumcheck halves, d + 1 for the GKR sumcheck)
     int mode;                // 0: message = the evaluations, big-endian (prover.rs:50-55)
                              // 1: message = Lagrange coefficients over 0..d, little-endian (sumcheck_gkr_protocol.rs:46-52)
-    int with_claim;          // mode 0, round 0: absorb evals[0] + evals[1] first (prover.rs:28,40-41)
     DevSponge *sponge;
     const void *basis;       // mode 1: basis[i * npts + d] = coefficient d of l_i (Montgomery form), followed by the same
                              // npts^2 coefficients as canonical integers (ev * canonical = canonical product)
     void *proof;             // Fe slots
+};
+
+template <class F> struct RoundShared {                      // LDS of the transcript step
+    Fe<F> ev[kMaxPts];
+    Fe<F> pr[2 * kMaxPts * kMaxPts];
+    Fe<F> chal;
+    uint32_t msg[(kMaxPts + 1) * F::N + 8];
+    uint64_t st[25], cl[25], tmp[25];
+};
+
+// Wave 0, uniform control flow.  In: S.ev[0 .. npts) and the sponge in S.st / fill.  Forms the round message, stores it in
+// the proof slots, absorbs it, samples; the challenge goes to proof[chal_slot] and to S.chal.
+template <class F>
+__device__ __forceinline__ void round_message_and_challenge(RoundShared<F> &S, const RoundCtx &c, int with_claim, size_t claim_slot,
+                                                            size_t msg_slot, size_t chal_slot, uint32_t &fill, unsigned lane) {
+    const int npts = c.npts;
+    const int nmsg = npts + (with_claim ? 1 : 0);
+    if (c.mode == 0) {
+        if ((int)lane < nmsg) {
+            const int t = (int)lane;
+            Fe<F> m;
+            size_t slot;
+            if (with_claim && t == 0) { m = fe_add<F>(S.ev[0], S.ev[1]); slot = claim_slot; }      // prover.rs:28,40-41
+            else { int k = t - (with_claim ? 1 : 0); m = S.ev[k]; slot = msg_slot + k; }
+            fe_store<F>(c.proof, slot, m);
+            Fe<F> cn = fe_to_canonical<F>(m);
+#pragma unroll
+            for (int k = 0; k < F::N; k++) S.msg[t * F::N + k] = __builtin_bswap32(cn.l[F::N - 1 - k]);
+        }
+    } else {
+        // coefficient d = sum_i ev[i] * basis[i][d]: the npts^2 products in the stored form and the npts^2 canonical ones
+        // (for the bytes) are taken by 2 npts^2 lanes at once, then npts + npts lanes add them up
+        const int n2 = npts * npts;
+        if ((int)lane < 2 * n2) S.pr[lane] = fe_mul<F>(S.ev[((int)lane % n2) / npts], fe_load<F>(c.basis, lane));
+        wave_lds_sync();
+        if ((int)lane < 2 * npts) {
+            const int which = (int)lane / npts, d = (int)lane % npts;
+            Fe<F> m = S.pr[which * n2 + d];
+#pragma unroll 1
+            for (int i = 1; i < npts; i++) m = fe_add<F>(m, S.pr[which * n2 + i * npts + d]);
+            if (which == 0) fe_store<F>(c.proof, msg_slot + d, m);
+            else {
+#pragma unroll
+                for (int k = 0; k < F::N; k++) S.msg[d * F::N + k] = m.l[k];
+            }
+        }
+    }
+    wave_lds_sync();
+    TS(2);
+    const unsigned nbytes = (unsigned)nmsg * 4u * F::N;
+    sponge_absorb_sample_wave(S.st, S.cl, S.tmp, fill, S.msg, nbytes, lane);
+    TS(3);
+    if (lane == 0) {
+        Fe<F> ch = challenge_from_digest<F>(S.msg + (nbytes >> 2));
+        fe_store<F>(c.proof, chal_slot, ch);
+        S.chal = ch;
+    }
+    wave_lds_sync();
+}
+
+struct FinishArgs {
+    const void *partials;    // [t * count + block], t < npts
+    size_t count;
+    RoundCtx ctx;
+    int with_claim;          // mode 0, round 0: absorb evals[0] + evals[1] first (prover.rs:28,40-41)
     size_t claim_slot, msg_slot, chal_slot;
 };
 
-constexpr int kMaxPts = kMaxFactors + 1;
-
 // One workgroup (64..1024 lanes, a multiple of 64).  Stage 1: every wave reduces its share of the partials, all npts
-// sums interleaved (independent shuffle chains).  Everything after the single __syncthreads runs in wave 0: the
-// cross-wave sums (16-lane groups), the round message, the transcript step and the challenge.
+// sums interleaved.  Everything after the single __syncthreads runs in wave 0: the cross-wave sums (16-lane
+// groups), the round message, the transcript step and the challenge.
 template <class F>
 __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArgs a) {
     __shared__ Wide<F> sh[kMaxPts * 16];                     // [t * 16 + wave]
-    __shared__ Fe<F> ev[kMaxPts];
-    __shared__ Fe<F> pr[2 * kMaxPts * kMaxPts];
-    __shared__ uint32_t msg[(kMaxPts + 1) * F::N + 8];
-    __shared__ uint64_t st[25], cl[25], tmp[25];
+    __shared__ RoundShared<F> S;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int npts = a.npts;
+    const int npts = a.ctx.npts;
     TS(0);
     Wide<F> acc[kMaxPts];                                    // lazy sums (mle_kernels.cuh); unused ones stay zero
 #pragma unroll
@@ -187,66 +247,102 @@ __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArg
 #pragma unroll
         for (int t = 0; t < kMaxPts; t++) sh[t * 16 + wave] = acc[t];
     }
-    if (tid < 25) st[tid] = a.sponge->a[tid];
+    if (tid < 25) S.st[tid] = a.ctx.sponge->a[tid];
     __syncthreads();
     if (wave != 0) return;
     {   // cross-wave sums: lane t * 16 + w holds wave w's sum of evaluation t
         const unsigned t = lane >> 4, w = lane & 15u;
         Wide<F> v = w < nwaves ? sh[lane] : wide_zero<F>();
         row_reduce_wide<F>(v);                               // a 16-lane group is one DPP row: sum in its lane 15
-        if (w == 15 && (int)t < npts) ev[t] = wide_reduce<F>(v);
+        if (w == 15 && (int)t < npts) S.ev[t] = wide_reduce<F>(v);
         wave_lds_sync();
     }
     TS(1);
-    const int nmsg = npts + (a.with_claim ? 1 : 0);
-    if (a.mode == 0) {
-        if ((int)lane < nmsg) {
-            const int t = (int)lane;
-            Fe<F> m;
-            size_t slot;
-            if (a.with_claim && t == 0) { m = fe_add<F>(ev[0], ev[1]); slot = a.claim_slot; }
-            else { int k = t - (a.with_claim ? 1 : 0); m = ev[k]; slot = a.msg_slot + k; }
-            fe_store<F>(a.proof, slot, m);
-            Fe<F> c = fe_to_canonical<F>(m);
-#pragma unroll
-            for (int k = 0; k < F::N; k++) msg[t * F::N + k] = __builtin_bswap32(c.l[F::N - 1 - k]);
-        }
-    } else {
-        // coefficient d = sum_i ev[i] * basis[i][d]: the npts^2 products in the stored form and the npts^2 canonical ones
-        // (for the bytes) are taken by 2 npts^2 lanes at once, then npts + npts lanes add them up
-        const int n2 = npts * npts;
-        if ((int)lane < 2 * n2) pr[lane] = fe_mul<F>(ev[((int)lane % n2) / npts], fe_load<F>(a.basis, lane));
-        wave_lds_sync();
-        if ((int)lane < 2 * npts) {
-            const int which = (int)lane / npts, d = (int)lane % npts;
-            Fe<F> m = pr[which * n2 + d];
-#pragma unroll 1
-            for (int i = 1; i < npts; i++) m = fe_add<F>(m, pr[which * n2 + i * npts + d]);
-            if (which == 0) fe_store<F>(a.proof, a.msg_slot + d, m);
-            else {
-#pragma unroll
-                for (int k = 0; k < F::N; k++) msg[d * F::N + k] = m.l[k];
-            }
-        }
-    }
-    wave_lds_sync();
-    TS(2);
-    uint32_t fill = a.sponge->fill;
-    const unsigned nbytes = (unsigned)nmsg * 4u * F::N;
-    sponge_absorb_sample_wave(st, cl, tmp, fill, msg, nbytes, lane);
-    TS(3);
-    if (lane < 25) a.sponge->a[lane] = st[lane];
-    if (lane == 0) {
-        a.sponge->fill = fill;
-        fe_store<F>(a.proof, a.chal_slot, challenge_from_digest<F>(msg + (nbytes >> 2)));
-    }
+    uint32_t fill = a.ctx.sponge->fill;
+    round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_slot, a.chal_slot, fill, lane);
+    if (lane < 25) a.ctx.sponge->a[lane] = S.st[lane];
+    if (lane == 0) a.ctx.sponge->fill = fill;
     TS(4);
 }
 
-// element 0 of each table -> proof slots (the fully folded values after the last round)
-template <class F> __global__ void gather_first_kernel(SumPolyTables tabs, int ntab, void *proof, size_t slot) {
-    int k = threadIdx.x;
-    if (k < ntab) fe_store<F>(proof, slot + k, fe_load<F>(tabs.in[k], 0));
+// ---- tail of a sumcheck: every round from a table of <= 4 kTailBlock entries down to one entry in ONE launch ----------
+// Below ~2^11 entries a round is pure latency (one lane's chain of ~16 dependent products + the transcript step); as two
+// launches per round it costs ~36 us, most of it launch, partial-sum round trip and a second reduction.  One workgroup keeps
+// the sponge in LDS, folds + evaluates (lane i owns pair index i), reduces straight to the evaluations, runs the
+// transcript step in wave 0 and broadcasts the challenge through LDS.  Same arithmetic, same bytes absorbed.
+constexpr int kTailBlock = 512;
+constexpr size_t kTailLen = 4 * (size_t)kTailBlock;
+
+struct TailArgs {
+    SumPolyTables tabs;      // in[k]: current tables of `len` entries
+    void *buf[2];            // ping-pong storage: round j writes table k at buf[j & 1] + k * (out length) elements
+    int nprod, ntab;
+    size_t len;              // 2 .. 4 * kTailBlock (kTailLen), a power of two
+    RoundCtx ctx;
+    size_t round;            // index of the round whose challenge folds `in` (already in proof[chal_base + per * round])
+    size_t msg_base, chal_base, per;   // slots of round k: messages at msg_base + per k, challenge at chal_base + per k
+    size_t fin_slot;         // ntab final values (only written when fin_slot != ~0)
+};
+
+template <class F, int NFAC>
+__global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
+    __shared__ Wide<F> sh[(NFAC + 1) * kTailBlock / 64];
+    __shared__ RoundShared<F> S;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const size_t esz = 4 * F::N;
+    if (tid < 25) S.st[tid] = a.ctx.sponge->a[tid];
+    uint32_t fill = a.ctx.sponge->fill;
+    Fe<F> r = fe_load<F>(a.ctx.proof, a.chal_base + a.per * a.round);
+    // table k of the current round: the caller's tables first, then slice k of the previous round's output buffer
+    const char *prev = nullptr;
+    size_t cl = a.len, round = a.round;
+    int j = 0;
+    __syncthreads();
+    while (cl >= 4) {                                        // fold by r AND evaluate the next round (sumcheck_kernels.cuh)
+        const size_t q = cl / 4, ol = cl / 2;
+        char *dst = (char *)a.buf[j & 1];
+        Wide<F> acc[NFAC + 1];
+#pragma unroll
+        for (int t = 0; t <= NFAC; t++) acc[t] = wide_zero<F>();
+        if (tid < q) {
+            const Multiplier<F> mr(r);
+            for (int p = 0; p < a.nprod; p++) {
+                Fe<F> lo[NFAC], hi[NFAC];
+#pragma unroll
+                for (int f = 0; f < NFAC; f++) {
+                    const void *src = prev ? (const void *)(prev + (size_t)(p * NFAC + f) * cl * esz) : a.tabs.in[p * NFAC + f];
+                    void *out = dst + (size_t)(p * NFAC + f) * ol * esz;
+                    Fe<F> a0 = fe_load<F>(src, tid), a1 = fe_load<F>(src, tid + q);
+                    Fe<F> b0 = fe_load<F>(src, tid + 2 * q), b1 = fe_load<F>(src, tid + 3 * q);
+                    lo[f] = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
+                    hi[f] = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
+                    fe_store<F>(out, tid, lo[f]);
+                    fe_store<F>(out, tid + q, hi[f]);
+                }
+                accumulate_terms<F, NFAC>(lo, hi, acc);
+            }
+        }
+        Fe<F> tot;
+        if (block_reduce_wide<F, NFAC + 1>(acc, sh, tot)) S.ev[tid] = tot;
+        __syncthreads();
+        round++;
+        if (tid < 64) round_message_and_challenge<F>(S, a.ctx, 0, 0, a.msg_base + a.per * round, a.chal_base + a.per * round, fill, lane);
+        __syncthreads();                                     // also orders this round's global stores before the next round's loads
+        r = S.chal;
+        prev = dst;
+        cl = ol;
+        j++;
+    }
+    if (cl == 2 && (int)tid < a.ntab) {                      // last round: 2 entries -> 1 (nothing left to sum)
+        const Multiplier<F> mr(r);
+        const void *src = prev ? (const void *)(prev + (size_t)tid * cl * esz) : a.tabs.in[tid];
+        Fe<F> y1 = fe_load<F>(src, 0), y2 = fe_load<F>(src, 1);
+        Fe<F> v = fe_add<F>(y1, mr.times(fe_sub<F>(y2, y1)));
+        fe_store<F>((char *)a.buf[j & 1] + (size_t)tid * esz, 0, v);
+        if (a.fin_slot != ~(size_t)0) fe_store<F>(a.ctx.proof, a.fin_slot + tid, v);
+    }
+    if (tid < 25) a.ctx.sponge->a[tid] = S.st[tid];
+    if (tid == 0) a.ctx.sponge->fill = fill;
 }
 
 }  // namespace zk

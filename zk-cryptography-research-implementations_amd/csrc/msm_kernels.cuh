@@ -217,21 +217,6 @@ __global__ void msm_scatter_kernel(const uint16_t *__restrict__ digits, size_t n
     }
 }
 
-// ---- setup-side kernels ----------------------------------------------------------------------------
-// eq / Lagrange table  L_idx(tau) = prod_i (bit_i(idx) ? tau_i : 1 - tau_i), variable 0 = MSB
-// (compute_lagrange_basis trusted_setup.rs:24-49), built level by level: out has 2 * len entries,
-// out[2 j] = in[j] * (1 - tau), out[2 j + 1] = in[j] * tau.
-__global__ void eq_expand_kernel(const void *__restrict__ in, void *__restrict__ out, size_t len, Fe<Fr381> tau) {
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    Fe<Fr381> omt = fe_sub<Fr381>(fe_one<Fr381>(), tau);
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride) {
-        Fe<Fr381> v = fe_load<Fr381>(in, j);
-        fe_store<Fr381>(out, 2 * j, fe_mul<Fr381>(v, omt));
-        fe_store<Fr381>(out, 2 * j + 1, fe_mul<Fr381>(v, tau));
-    }
-}
-
-
 // ---- two-level scatter for wide windows (c >= 12) --------------------------------------------------------------
 // The single-pass scatter above writes 4-byte entries to 2^(c-1) open runs per window at once: at 2^24 terms it is
 // write-amplification bound (6.4 ms).  Here entries are first partitioned by the HIGH bits of the bucket id

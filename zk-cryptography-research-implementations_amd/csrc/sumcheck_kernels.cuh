@@ -106,18 +106,6 @@ __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables 
     write_partials<F, NFAC>(acc, sh, partials);
 }
 
-// plain fold of every table (used for the last round, 2-entry tables)
-template <class F>
-__global__ void fold_all_kernel(SumPolyTables tabs, int ntab, size_t half, Fe<F> r, const void *__restrict__ rp = nullptr) {
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    const Multiplier<F> mr(challenge_arg<F>(r, rp));
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride)
-        for (int k = 0; k < ntab; k++) {
-            Fe<F> y1 = fe_load<F>(tabs.in[k], i), y2 = fe_load<F>(tabs.in[k], i + half);
-            fe_store<F>(tabs.out[k], i, fe_add<F>(y1, mr.times(fe_sub<F>(y2, y1))));
-        }
-}
-
 // element-wise reduce of a SumPolynomial to one table: out[i] = sum_p prod_f X[p][f][i]
 // (add_polynomials_element_wise sum_polynomial.rs:57-76 over multiply_polynomials_element_wise
 //  product_polynomial.rs:58-73)

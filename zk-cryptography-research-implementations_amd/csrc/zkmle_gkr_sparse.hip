@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "context.h"
+#include "eq_table.cuh"
 #include "sumcheck_kernels.cuh"
 #include "transcript.h"
 
@@ -43,16 +44,6 @@ int alloc_table(int field, size_t len, TablePtr &out) {
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------
-// eq table: out[2j] = in[j] (1 - tau), out[2j+1] = in[j] tau  (variable 0 = MSB first)
-template <class F> __global__ void eq_expand_kernel_t(const void *__restrict__ in, void *__restrict__ out, size_t len, Fe<F> tau) {
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    Fe<F> omt = fe_sub<F>(fe_one<F>(), tau);
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride) {
-        Fe<F> v = fe_load<F>(in, j);
-        fe_store<F>(out, 2 * j, fe_mul<F>(v, omt));
-        fe_store<F>(out, 2 * j + 1, fe_mul<F>(v, tau));
-    }
-}
 template <class F> __global__ void fill_one_kernel(void *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) fe_store<F>(out, i, fe_one<F>());
@@ -177,25 +168,11 @@ int upload_layer(const zk_gate *g, size_t n, uint32_t out_bits, uint32_t in_bits
 
 inline unsigned blocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-// eq(point, .) over 2^nbits entries, built level by level in HBM
+// eq(point, .) over 2^nbits entries: outer products of the half tables (eq_table.cuh), a handful of launches
 template <class F> int eq_table(const uint64_t *point, uint32_t nbits, TablePtr &out) {
-    size_t n = (size_t)1 << nbits;
-    TablePtr a, b;
-    ZK_TRY(alloc_table(F::ID, n, a));
-    ZK_TRY(alloc_table(F::ID, n, b));
-    Fe<F> one = fe_one<F>();
-    ZK_HIP(hipMemcpy(a->dptr, one.l, 4 * F::N, hipMemcpyHostToDevice));
-    zk_table *cur = a.get(), *nxt = b.get();
-    size_t len = 1;
-    for (uint32_t i = 0; i < nbits; i++) {
-        eq_expand_kernel_t<F><<<grid_for(len), kBlock>>>(cur->dptr, nxt->dptr, len, load_el<F>(point + (size_t)i * (F::N / 2)));
-        ZK_HIP(hipGetLastError());
-        zk_table *t = cur; cur = nxt; nxt = t;
-        len *= 2;
-    }
-    if (cur == a.get()) out = std::move(a); else out = std::move(b);
-    out->len = n;
-    return ZK_OK;
+    ZK_TRY(alloc_table(F::ID, (size_t)1 << nbits, out));
+    EqBuilder<F> eb;
+    return eb.build(point, nbits, out->dptr);
 }
 
 template <class F> int evaluate_layers(std::vector<LayerDev> &layers, const uint64_t *inputs, size_t ninputs, std::vector<TablePtr> &W) {

@@ -9,6 +9,7 @@
 
 #include "context.h"
 #define ZK_MSM_LIGHT_KERNELS
+#include "eq_table.cuh"
 #include "msm_kernels.cuh"
 
 using namespace zk;
@@ -284,25 +285,13 @@ int generator_table(const void **out) {
 int lagrange_basis_device(const uint64_t *taus, size_t ntaus, zk_table **out) {
     if (!taus || ntaus == 0 || ntaus > 40) return ZK_E_ARG;       // "requires at least one variable" trusted_setup.rs:26
     size_t n = (size_t)1 << ntaus;
-    zk_table *a = nullptr, *b = nullptr;
-    ZK_TRY(zk_table_alloc(ZK_FR381, n, &a));
-    int rc = zk_table_alloc(ZK_FR381, n, &b);
-    if (rc != ZK_OK) { zk_table_free(a); return rc; }
-    Fe<Fr381> one = fe_one<Fr381>();
-    hipError_t e = hipMemcpy(a->dptr, one.l, 32, hipMemcpyHostToDevice);
-    zk_table *cur = a, *nxt = b;
-    size_t len = 1;
-    for (size_t i = 0; i < ntaus && e == hipSuccess; i++) {       // variable 0 (MSB) first: index bit (n-1-i), :36
-        eq_expand_kernel<<<grid_for(len), kBlock>>>(cur->dptr, nxt->dptr, len, load_el<Fr381>(taus + 4 * i));
-        e = hipGetLastError();
-        zk_table *t = cur; cur = nxt; nxt = t;
-        len *= 2;
-    }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    zk_table_free(nxt);
-    if (e != hipSuccess) { zk_table_free(cur); ZK_HIP(e); }
-    cur->len = n;
-    *out = cur;
+    zk_table *t = nullptr;
+    ZK_TRY(zk_table_alloc(ZK_FR381, n, &t));
+    EqBuilder<Fr381> eb;                                          // variable 0 = MSB (:36); outer products of half tables
+    int rc = eb.build(taus, (uint32_t)ntaus, t->dptr);
+    if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = ZK_E_HIP;
+    if (rc != ZK_OK) { zk_table_free(t); return rc; }
+    *out = t;
     return ZK_OK;
 }
 

@@ -4,6 +4,8 @@
 #include <string.h>
 
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "context.h"
@@ -83,15 +85,27 @@ template <class F> struct DeviceRounds {
         ZK_HIP(hipMemcpy(buf.p, host.data(), host.size(), hipMemcpyHostToDevice));
         return ZK_OK;
     }
+    RoundCtx ctx(int npts, int mode) const { return RoundCtx{npts, mode, sponge(), basis(), proof()}; }
     int launch_finish(const void *partials, size_t count, int npts, int mode, int with_claim, size_t claim_slot, size_t msg_slot,
                       size_t chal_slot) {
         FinishArgs a{};
-        a.partials = partials; a.count = count; a.npts = npts; a.mode = mode; a.with_claim = with_claim;
-        a.sponge = sponge(); a.basis = basis(); a.proof = proof();
+        a.partials = partials; a.count = count; a.ctx = ctx(npts, mode); a.with_claim = with_claim;
         a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
         size_t threads = (count + 63) / 64 * 64;          // one partial per lane up to 1024 lanes
         if (threads > (size_t)kFinishBlock) threads = kFinishBlock;
         sumcheck_finish_kernel<F><<<1, (int)threads>>>(a);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    // every remaining round of a sumcheck whose tables have <= kTailLen entries, one launch (dev_transcript.cuh)
+    int launch_tail(const SumPolyTables &tabs, void *buf0, void *buf1, int nprod, int nfac, size_t len, int mode, size_t round,
+                    size_t msg_base, size_t chal_base, size_t per, size_t fin_slot) {
+        TailArgs a{};
+        a.tabs = tabs; a.buf[0] = buf0; a.buf[1] = buf1; a.nprod = nprod; a.ntab = nprod * nfac; a.len = len;
+        a.ctx = ctx(nfac + 1, mode); a.round = round; a.msg_base = msg_base; a.chal_base = chal_base; a.per = per; a.fin_slot = fin_slot;
+        if (nfac == 1) sumcheck_tail_kernel<F, 1><<<1, kTailBlock>>>(a);
+        else if (nfac == 2) sumcheck_tail_kernel<F, 2><<<1, kTailBlock>>>(a);
+        else sumcheck_tail_kernel<F, 3><<<1, kTailBlock>>>(a);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
@@ -148,23 +162,24 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
     const void *cur = table->dptr;
     void *dst = bufA.p, *other = bufB.p;
     size_t cl = len;
-    for (unsigned round = 0; round < nvars; round++) {                 // :46
+    unsigned round = 0;
+    for (; cl > kTailLen; round++) {                                   // :46
         const void *rp = dr.slot_ptr(3 + 3 * (size_t)round);           // this round's challenge (:58), on the device
-        if (cl >= 4) {                                                 // :61-63 fused with the next round's :50
-            size_t q = cl / 4;
-            int grid = reduce_grid_for(q);
-            fold_half_sums_kernel<F><<<grid, kBlock>>>(cur, dst, q, fe_zero<F>(), part, rp);
-            ZK_HIP(hipGetLastError());
-            ZK_TRY(dr.launch_finish(part, (size_t)grid, 2, 0, 0, 0, 1 + 3 * (size_t)(round + 1), 3 + 3 * (size_t)(round + 1)));
-        } else {                                                       // 2 entries -> 1: nothing left to sum
-            fold_kernel<F><<<1, kBlock>>>(cur, dst, 1, 0, fe_zero<F>(), rp);
-            ZK_HIP(hipGetLastError());
-        }
+        size_t q = cl / 4;                                             // :61-63 fused with the next round's :50
+        int grid = reduce_grid_for(q);
+        fold_half_sums_kernel<F><<<grid, kBlock>>>(cur, dst, q, fe_zero<F>(), part, rp);
+        ZK_HIP(hipGetLastError());
+        ZK_TRY(dr.launch_finish(part, (size_t)grid, 2, 0, 0, 0, 1 + 3 * (size_t)(round + 1), 3 + 3 * (size_t)(round + 1)));
         cur = dst;
         void *nx = other;
         other = dst;
         dst = nx;
         cl /= 2;
+    }
+    {   // rounds on <= kTailLen entries: one launch; the half sums are the evaluations at 0 and 1 of a 1-factor product
+        SumPolyTables tabs{};
+        tabs.in[0] = cur;
+        ZK_TRY(dr.launch_tail(tabs, dst, other, 1, 1, cl, 0, round, 1, 3, 3, ~(size_t)0));
     }
     ZK_TRY(dr.collect(tr));
     g_stats.ms_rounds = (float)(now_ms() - t1);
@@ -252,6 +267,27 @@ template <class F> int round_evals(const zk_table *const *tables, size_t nprod, 
     return ZK_OK;
 }
 
+// The interpolation nodes of the GKR sumcheck are always 0..d (sumcheck_gkr_protocol.rs:46-48), so the Lagrange basis
+// (d + 1 host inversions, ~0.15 ms) is built once per (field, d) and kept: Montgomery form, then canonical integers
+// (FinishArgs::basis).
+template <class F> const std::vector<Fe<F>> &sumcheck_basis(size_t npts) {
+    static std::mutex mu;
+    static std::map<size_t, std::vector<Fe<F>>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(npts);
+    if (it != cache.end()) return it->second;
+    std::vector<Fe<F>> xs(npts);
+    for (size_t i = 0; i < npts; i++) xs[i] = fe_from_u64<F>(i);
+    const std::vector<std::vector<Fe<F>>> basis = lagrange_basis_matrix<F>(xs);
+    std::vector<Fe<F>> flat(2 * npts * npts);
+    for (size_t i = 0; i < npts; i++)
+        for (size_t d = 0; d < npts; d++) {
+            flat[i * npts + d] = basis[i][d];
+            flat[npts * npts + i * npts + d] = fe_to_canonical<F>(basis[i][d]);
+        }
+    return cache.emplace(npts, std::move(flat)).first->second;
+}
+
 // ---- GKR sumcheck prover: sumcheck_gkr_protocol.rs:24-67 --------------------------------------------------
 template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t nprod, size_t nfac, Transcript &tr,
                                            uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values) {
@@ -269,15 +305,7 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
     ZK_TRY(bufB.alloc(ntab * (len / 4) * esz));
     void *part;
     ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
-    std::vector<Fe<F>> xs(npts);
-    for (size_t i = 0; i < npts; i++) xs[i] = fe_from_u64<F>(i);       // :46-48
-    const std::vector<std::vector<Fe<F>>> basis = lagrange_basis_matrix<F>(xs);   // nodes 0..d never change
-    std::vector<Fe<F>> basis_flat(2 * npts * npts);        // Montgomery form, then the canonical integers (FinishArgs::basis)
-    for (size_t i = 0; i < npts; i++)
-        for (size_t d = 0; d < npts; d++) {
-            basis_flat[i * npts + d] = basis[i][d];
-            basis_flat[npts * npts + i * npts + d] = fe_to_canonical<F>(basis[i][d]);
-        }
+    const std::vector<Fe<F>> &basis_flat = sumcheck_basis<F>(npts);    // :46-50, nodes 0..d never change
     // Proof slots: round k: (npts+1)k .. +npts-1 = coefficients (:49-52), +npts = challenge (:55); then ntab final values.
     // Interpolation, absorb and challenge of every round run in the finish kernel (dev_transcript.cuh).
     const size_t per = npts + 1, fin_slot = per * nvars;
@@ -294,27 +322,22 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
     }
     char *dst = (char *)bufA.p, *other = (char *)bufB.p;
     size_t cl = len;
-    for (unsigned round = 0; round < nvars; round++) {                 // :37
+    unsigned round = 0;
+    for (; cl > kTailLen; round++) {                                   // :37
         const void *rp = dr.slot_ptr(per * round + npts);              // :55, on the device
-        size_t ol = cl / 2;
+        size_t ol = cl / 2, q = cl / 4;
         for (size_t k = 0; k < ntab; k++) tabs.out[k] = dst + k * ol * esz;
-        if (cl >= 4) {                                                 // :57 fused with next round's :41
-            size_t q = cl / 4;
-            int grid = reduce_grid_for(q);
-            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp)));
-            ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, per * (round + 1), per * (round + 1) + npts));
-        } else {
-            fold_all_kernel<F><<<1, kBlock>>>(tabs, (int)ntab, 1, fe_zero<F>(), rp);
-            ZK_HIP(hipGetLastError());
-        }
+        int grid = reduce_grid_for(q);                                 // :57 fused with next round's :41
+        ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp)));
+        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, per * (round + 1), per * (round + 1) + npts));
         for (size_t k = 0; k < ntab; k++) tabs.in[k] = tabs.out[k];
         char *nx = other;
         other = dst;
         dst = nx;
         cl = ol;
     }
-    gather_first_kernel<F><<<1, 64>>>(tabs, (int)ntab, dr.proof(), fin_slot);
-    ZK_HIP(hipGetLastError());
+    // rounds on <= kTailLen entries, the last fold and the final values: one launch
+    ZK_TRY(dr.launch_tail(tabs, dst, other, (int)nprod, (int)nfac, cl, 1, round, 0, npts, per, fin_slot));
     ZK_TRY(dr.collect(tr));
     g_stats = zk_sumcheck_stats{nvars, 0.f, (float)(now_ms() - t1)};
     for (unsigned round = 0; round < nvars; round++) {
