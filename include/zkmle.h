@@ -179,6 +179,36 @@ int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_
                            size_t nrounds, size_t ncoef, zk_transcript *t, uint64_t *challenges,
                            uint64_t *last_claimed_sum, int *ok);
 
+/* ---- device-resident rounds as a handle: sharded (one process per GPU) sumcheck provers ------------------
+ * each GPU owns the table entries i == rank (mod G); a round is local except for the sum of 2 (basic) or
+ * d + 1 (GKR) evaluations over the ranks.  With this handle that sum is ONE all-reduce(SUM) of `zk_rounds_limbs_len`
+ * 64-bit words in device memory (RCCL; each word holds a 32-bit limb of a lazy sum, so element-wise integer
+ * addition is exact), and the transcript step runs on every rank's device (csrc/dev_transcript.cuh): no host round
+ * trip per round.  Sequence: zk_rounds_evals -> all-reduce -> zk_rounds_absorb, then per round zk_rounds_fold_evals
+ * -> all-reduce -> zk_rounds_absorb; when one entry per rank is left, gather the G entries on every rank,
+ * zk_rounds_evals + zk_rounds_absorb on the gathered tables (no all-reduce: replicated) and zk_rounds_tail.
+ * mode 0 = basic sumcheck (prover.rs:35-71; nprod = nfac = 1, messages = the two half sums, the claimed sum is
+ * absorbed before round 0), mode 1 = GKR sumcheck rounds (sumcheck_gkr_protocol.rs:37-60).  `t` is read at creation
+ * (everything absorbed so far) and written back by zk_rounds_collect. */
+typedef struct zk_rounds zk_rounds;
+int zk_rounds_new(int field, int mode, size_t nprod, size_t nfac, size_t nrounds, zk_transcript *t, zk_rounds **out);
+int zk_rounds_free(zk_rounds *r);
+size_t zk_rounds_limbs_len(const zk_rounds *r);                     /* (nfac + 1) * (limbs32 + 1) words */
+/* evaluations of the next round from the CURRENT tables (no fold) -> limbs_dev (device memory) */
+int zk_rounds_evals(zk_rounds *r, const zk_table *const *tables, uint64_t *limbs_dev);
+/* fold every table by the last absorbed round's challenge (device-resident) into `out`, and the next round's
+ * evaluations -> limbs_dev; tables of 2 entries are only folded (limbs_dev untouched, may be NULL) */
+int zk_rounds_fold_evals(zk_rounds *r, const zk_table *const *in, zk_table *const *out, uint64_t *limbs_dev);
+/* transcript step of the next round on the (summed) limbs: message, absorb, challenge */
+int zk_rounds_absorb(zk_rounds *r, const uint64_t *limbs_dev);
+/* every remaining round in one launch on tables every rank holds in full (<= 2048 entries); the last absorbed
+ * round's challenge folds first */
+int zk_rounds_tail(zk_rounds *r, const zk_table *const *tables);
+/* the single synchronisation: messages (nrounds x (nfac + 1) elements), challenges (nrounds), the claimed sum
+ * (mode 0) and, after zk_rounds_tail, the nprod * nfac fully folded values; any pointer may be NULL */
+int zk_rounds_collect(zk_rounds *r, zk_transcript *t, uint64_t *claimed_sum, uint64_t *messages, uint64_t *challenges,
+                      uint64_t *final_values);
+
 /* ---- layered circuit + GKR prover (circuit/src/arithmetic_circuit.rs, gkr/src/gkr_protocol.rs) ----
  * Gate :9-15 (op 0 = Add, 1 = Mul); a circuit is `nlayers` layers (layer 0 = output layer), its
  * gates concatenated in `gates` with per-layer counts.  The reference ties width to depth: layer i

@@ -98,6 +98,14 @@ def run(rank, world, port, engine, field, table, sum_tables, claimed, scalars, p
         t.append(b"prefix")
         co, gch = S.sumcheck_gkr_prove(comm, mk_sum(sum_tables[:, :, rank::world]), claimed, t)
         res.update(gkr_coeffs=co, gkr_chal=gch, gkr_tail=np.frombuffer(t.sample_random_challenge(), np.uint8))
+        if engine == "gpu":        # the same proofs with the transcript on the device and one all-reduce per round
+            cs, rp, ch = S.sumcheck_basic_prove_device(comm, mk(S.shard_of(table, rank, world)))
+            res.update(dev_basic_claimed=cs, dev_basic_rounds=rp, dev_basic_chal=ch)
+            t = zk.Transcript()
+            t.append(b"prefix")
+            co, gch, fin = S.sumcheck_gkr_prove_device(comm, mk_sum(sum_tables[:, :, rank::world]), claimed, t)
+            res.update(dev_gkr_coeffs=co, dev_gkr_chal=gch, dev_gkr_final=fin,
+                       dev_gkr_tail=np.frombuffer(t.sample_random_challenge(), np.uint8))
         if scalars is not None:
             n = scalars.shape[0]
             lo, hi = rank * n // world, (rank + 1) * n // world           # slice sharding of the MSM terms

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 OPS = {"add": 0, "mul": 1}
 
 
-@pytest.mark.parametrize("world,logn", [(2, 2), (2, 10), (4, 9)])
+@pytest.mark.parametrize("world,logn", [(1, 3), (2, 1), (2, 2), (2, 10), (4, 2), (4, 9), (2, 14)])
 def test_sharded_provers_on_gpu(world, logn):
     field = O.FR381
     n = 1 << logn
@@ -25,6 +25,10 @@ def test_sharded_provers_on_gpu(world, logn):
     results = launch(world, "gpu", field, table, sum_tables, claimed, scalars, pts)
     want = expected(field, table, sum_tables, claimed)
     want["msm"] = O.kzg_commit(scalars, pts)
+    # device-resident rounds (zk_rounds: limb all-reduce + transcript on the GPU) give the same proofs
+    for k in ("basic_claimed", "basic_rounds", "basic_chal", "gkr_coeffs", "gkr_chal", "gkr_tail"):
+        want["dev_" + k] = want[k]
+    want["dev_gkr_final"] = np.stack([O.evaluate(field, sum_tables[p, f], want["gkr_chal"]) for p in range(2) for f in range(2)])
     check(results, want)
 
 

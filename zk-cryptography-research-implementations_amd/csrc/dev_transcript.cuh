@@ -265,6 +265,67 @@ __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArg
     TS(4);
 }
 
+// ---- sharded provers (one process per GPU): the transcript step split around the exchange --------------------------------
+// A rank reduces its partials to npts lazy sums and publishes them as (N + 1) 32-bit limbs spread over 64-bit words
+// (`limbs[t * (N + 1) + k]`): the sum over <= 2^32 ranks of such vectors is a plain element-wise integer sum, i.e. ONE
+// all-reduce(SUM, int64) over RCCL, with no carries to move between words.  Every rank then runs the same transcript step on
+// the summed limbs (carry, reduce mod p, message, absorb, challenge): replicated sponge, no broadcast, no host round trip.
+template <class F>
+__global__ void __launch_bounds__(kFinishBlock) partials_to_limbs_kernel(const void *__restrict__ partials, size_t count, int npts,
+                                                                          uint64_t *__restrict__ limbs) {
+    __shared__ Wide<F> sh[kMaxPts * 16];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    Wide<F> acc[kMaxPts];
+#pragma unroll
+    for (int t = 0; t < kMaxPts; t++) {
+        acc[t] = wide_zero<F>();
+        if (t < npts)
+            for (size_t i = tid; i < count; i += blockDim.x) wide_add_fe<F>(acc[t], fe_load<F>(partials, (size_t)t * count + i));
+    }
+    wave_reduce_wide<F, kMaxPts>(acc, npts);
+    if (lane == 63) {
+#pragma unroll
+        for (int t = 0; t < kMaxPts; t++) sh[t * 16 + wave] = acc[t];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const unsigned t = lane >> 4, w = lane & 15u;
+    Wide<F> v = w < nwaves ? sh[lane] : wide_zero<F>();
+    row_reduce_wide<F>(v);
+    if (w == 15 && (int)t < npts) {
+#pragma unroll
+        for (int k = 0; k <= F::N; k++) limbs[t * (F::N + 1) + k] = v.l[k];
+    }
+}
+
+struct LimbsFinishArgs {
+    const uint64_t *limbs;   // element-wise sums over the ranks of partials_to_limbs_kernel's output
+    RoundCtx ctx;
+    int with_claim;
+    size_t claim_slot, msg_slot, chal_slot;
+};
+template <class F> __global__ void __launch_bounds__(64) limbs_finish_kernel(LimbsFinishArgs a) {
+    __shared__ RoundShared<F> S;
+    const unsigned lane = threadIdx.x;
+    if (lane < 25) S.st[lane] = a.ctx.sponge->a[lane];
+    if ((int)lane < a.ctx.npts) {
+        Wide<F> w;
+        uint64_t c = 0;
+#pragma unroll
+        for (int k = 0; k <= F::N; k++) {                    // words hold sums of 32-bit limbs: propagate the carries
+            uint64_t v = a.limbs[lane * (F::N + 1) + k] + c;
+            w.l[k] = (uint32_t)v;
+            c = v >> 32;
+        }
+        S.ev[lane] = wide_reduce<F>(w);
+    }
+    wave_lds_sync();
+    uint32_t fill = a.ctx.sponge->fill;
+    round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_slot, a.chal_slot, fill, lane);
+    if (lane < 25) a.ctx.sponge->a[lane] = S.st[lane];
+    if (lane == 0) a.ctx.sponge->fill = fill;
+}
+
 // ---- tail of a sumcheck: every round from a table of <= 4 kTailBlock entries down to one entry in ONE launch ----------
 // Below ~2^11 entries a round is pure latency (one lane's chain of ~16 dependent products + the transcript step); as two
 // launches per round it costs ~36 us, most of it launch, partial-sum round trip and a second reduction.  One workgroup keeps

@@ -375,6 +375,129 @@ template <class F> int gkr_sumcheck_verify(const uint64_t *claimed_sum, const ui
     return ZK_OK;
 }
 
+// ---- device-resident rounds as a handle: sharded (one process per GPU) sumcheck provers -------------------------------------
+// The caller (zkmle_amd/sharded.py, or a Rust shim) owns the collective; this object owns the sponge, the proof slots and
+// the round counter.  Sequence per round: evals / fold_evals (local tables -> limb sums in device memory) ->
+// all-reduce(SUM, int64) over RCCL by the caller -> absorb (transcript step on the summed limbs, challenge stays on the device).
+struct RoundsBase {
+    virtual ~RoundsBase() {}
+    virtual size_t limbs_len() const = 0;
+    virtual int evals(const zk_table *const *tables, uint64_t *limbs) = 0;
+    virtual int fold_evals(const zk_table *const *in, zk_table *const *out, uint64_t *limbs) = 0;
+    virtual int absorb(const uint64_t *limbs) = 0;
+    virtual int tail(const zk_table *const *tables) = 0;
+    virtual int collect(zk_transcript *t, uint64_t *claimed_sum, uint64_t *messages, uint64_t *challenges, uint64_t *final_values) = 0;
+};
+
+template <class F> struct RoundsImpl : RoundsBase {
+    int mode;                                            // 0 basic (1 table, half sums, big-endian), 1 GKR sumcheck
+    size_t nprod, nfac, ntab, npts, nrounds;
+    size_t msg_base, chal_base, per, fin_slot;
+    size_t round = 0;                                    // rounds absorbed so far
+    bool tail_done = false;
+    DeviceRounds<F> dr;
+    DevBuf tailbuf;
+
+    int init(int mode_, size_t nprod_, size_t nfac_, size_t nrounds_, Transcript &tr) {
+        mode = mode_; nprod = nprod_; nfac = nfac_; ntab = nprod * nfac; npts = nfac + 1; nrounds = nrounds_;
+        if (mode == 0) { msg_base = 1; chal_base = 3; per = 3; fin_slot = 1 + 3 * nrounds; }
+        else { msg_base = 0; chal_base = npts; per = npts + 1; fin_slot = per * nrounds; }
+        static const std::vector<Fe<F>> none;
+        return dr.init(tr, mode == 1 ? sumcheck_basis<F>(npts) : none, fin_slot + ntab);
+    }
+    size_t limbs_len() const override { return npts * (F::N + 1); }
+    int check_tables(const zk_table *const *t, size_t minlen) const {
+        ZK_TRY(check_sumpoly(t, nprod, nfac));
+        if (t[0]->field != F::ID || t[0]->len < minlen) return ZK_E_ARG;
+        return ZK_OK;
+    }
+    int to_limbs(void *part, int grid, uint64_t *limbs) {
+        size_t threads = ((size_t)grid + 63) / 64 * 64;
+        if (threads > (size_t)kFinishBlock) threads = kFinishBlock;
+        partials_to_limbs_kernel<F><<<1, (int)threads>>>(part, (size_t)grid, (int)npts, limbs);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    int evals(const zk_table *const *tables, uint64_t *limbs) override {
+        ZK_TRY(check_tables(tables, 2));
+        if (!limbs || round >= nrounds) return ZK_E_ARG;
+        SumPolyTables tabs{};
+        for (size_t k = 0; k < ntab; k++) tabs.in[k] = tables[k]->dptr;
+        size_t half = tables[0]->len / 2;
+        int grid = reduce_grid_for(half);
+        void *part;
+        ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
+        ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
+        return to_limbs(part, grid, limbs);
+    }
+    int fold_evals(const zk_table *const *in, zk_table *const *out, uint64_t *limbs) override {
+        ZK_TRY(check_tables(in, 2));
+        if (!out || round == 0 || round > nrounds) return ZK_E_ARG;      // needs the challenge of an absorbed round
+        size_t len = in[0]->len;
+        for (size_t k = 0; k < ntab; k++)
+            if (!out[k] || out[k]->field != F::ID || out[k]->len < len / 2 || out[k]->dptr == in[k]->dptr) return ZK_E_ARG;
+        SumPolyTables tabs{};
+        for (size_t k = 0; k < ntab; k++) { tabs.in[k] = in[k]->dptr; tabs.out[k] = out[k]->dptr; }
+        const void *rp = dr.slot_ptr(chal_base + per * (round - 1));
+        if (len >= 4) {
+            if (!limbs) return ZK_E_ARG;
+            size_t q = len / 4;
+            int grid = reduce_grid_for(q);
+            void *part;
+            ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
+            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp)));
+            ZK_TRY(to_limbs(part, grid, limbs));
+        } else {                                                         // 2 entries -> 1: nothing left to evaluate
+            for (size_t k = 0; k < ntab; k++) {
+                fold_kernel<F><<<1, 64>>>(tabs.in[k], tabs.out[k], 1, 0, fe_zero<F>(), rp);
+                ZK_HIP(hipGetLastError());
+            }
+        }
+        for (size_t k = 0; k < ntab; k++) out[k]->len = len / 2;
+        return ZK_OK;
+    }
+    int absorb(const uint64_t *limbs) override {
+        if (!limbs || round >= nrounds) return ZK_E_ARG;
+        LimbsFinishArgs a{};
+        a.limbs = limbs; a.ctx = dr.ctx((int)npts, mode); a.with_claim = (mode == 0 && round == 0) ? 1 : 0;
+        a.claim_slot = 0; a.msg_slot = msg_base + per * round; a.chal_slot = chal_base + per * round;
+        limbs_finish_kernel<F><<<1, 64>>>(a);
+        ZK_HIP(hipGetLastError());
+        round++;
+        return ZK_OK;
+    }
+    // every remaining round on tables every rank holds in full (<= kTailLen entries); round `round - 1` was absorbed
+    int tail(const zk_table *const *tables) override {
+        ZK_TRY(check_tables(tables, 2));
+        size_t len = tables[0]->len;
+        if (len > kTailLen || round == 0 || round - 1 + ilog2(len) != nrounds) return ZK_E_ARG;
+        ZK_TRY(tailbuf.alloc(ntab * (len / 2 + len / 4 + 1) * 4 * F::N));
+        SumPolyTables tabs{};
+        for (size_t k = 0; k < ntab; k++) tabs.in[k] = tables[k]->dptr;
+        char *b0 = (char *)tailbuf.p, *b1 = b0 + ntab * (len / 2) * 4 * F::N;
+        ZK_TRY(dr.launch_tail(tabs, b0, b1, (int)nprod, (int)nfac, len, mode, round - 1, msg_base, chal_base, per, fin_slot));
+        round = nrounds;
+        tail_done = true;
+        return ZK_OK;
+    }
+    int collect(zk_transcript *t, uint64_t *claimed_sum, uint64_t *messages, uint64_t *challenges, uint64_t *final_values) override {
+        const size_t L64 = F::N / 2;
+        if (!t || round != nrounds) return ZK_E_ARG;
+        ZK_TRY(dr.collect(t->t));
+        if (claimed_sum && mode == 0) store_el<F>(claimed_sum, dr.slot(0));
+        for (size_t r = 0; r < nrounds; r++) {
+            if (messages)
+                for (size_t i = 0; i < npts; i++) store_el<F>(messages + (r * npts + i) * L64, dr.slot(msg_base + per * r + i));
+            if (challenges) store_el<F>(challenges + r * L64, dr.slot(chal_base + per * r));
+        }
+        if (final_values) {
+            if (!tail_done) return ZK_E_ARG;
+            for (size_t k = 0; k < ntab; k++) store_el<F>(final_values + k * L64, dr.slot(fin_slot + k));
+        }
+        return ZK_OK;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -540,5 +663,50 @@ int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_
     ZK_DISPATCH_FIELD(field, return gkr_sumcheck_verify<F>(claimed_sum, round_coeffs, nrounds, ncoef, t->t, challenges, last_claimed_sum, ok));
     return ZK_OK;
 }
+
+struct zk_rounds {
+    RoundsBase *impl;
+};
+
+int zk_rounds_new(int field, int mode, size_t nprod, size_t nfac, size_t nrounds, zk_transcript *t, zk_rounds **out) {
+    if (!t || !out || nrounds == 0 || (mode != 0 && mode != 1)) return ZK_E_ARG;
+    if (nprod == 0 || nfac == 0 || nprod > (size_t)kMaxProducts || nfac > (size_t)kMaxFactors) return ZK_E_ARG;
+    if (mode == 0 && (nprod != 1 || nfac != 1)) return ZK_E_ARG;
+    if (mode == 1 && (nprod < 2 || nfac < 2)) return ZK_E_NEED_TWO;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(field, {
+        auto *r = new RoundsImpl<F>();
+        int rc = r->init(mode, nprod, nfac, nrounds, t->t);
+        if (rc != ZK_OK) { delete r; return rc; }
+        *out = new zk_rounds{r};
+    });
+    return ZK_OK;
+}
+int zk_rounds_free(zk_rounds *r) {
+    if (r) { delete r->impl; delete r; }
+    return ZK_OK;
+}
+size_t zk_rounds_limbs_len(const zk_rounds *r) { return r ? r->impl->limbs_len() : 0; }
+int zk_rounds_evals(zk_rounds *r, const zk_table *const *tables, uint64_t *limbs_dev) {
+    if (!r || !tables) return ZK_E_ARG;
+    return r->impl->evals(tables, limbs_dev);
+}
+int zk_rounds_fold_evals(zk_rounds *r, const zk_table *const *in, zk_table *const *out, uint64_t *limbs_dev) {
+    if (!r || !in) return ZK_E_ARG;
+    return r->impl->fold_evals(in, out, limbs_dev);
+}
+int zk_rounds_absorb(zk_rounds *r, const uint64_t *limbs_dev) {
+    if (!r) return ZK_E_ARG;
+    return r->impl->absorb(limbs_dev);
+}
+int zk_rounds_tail(zk_rounds *r, const zk_table *const *tables) {
+    if (!r || !tables) return ZK_E_ARG;
+    return r->impl->tail(tables);
+}
+int zk_rounds_collect(zk_rounds *r, zk_transcript *t, uint64_t *claimed_sum, uint64_t *messages, uint64_t *challenges, uint64_t *final_values) {
+    if (!r) return ZK_E_ARG;
+    return r->impl->collect(t, claimed_sum, messages, challenges, final_values);
+}
+
 
 }  // extern "C"

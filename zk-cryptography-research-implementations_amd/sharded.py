@@ -56,6 +56,19 @@ def _declare_host():
     lib.zk_g1_add.restype = C.c_int
     lib.zk_sumpoly_fold_round_evals.argtypes = [C.POINTER(L.vp), C.POINTER(L.vp), L.sz, L.sz, u64p, u64p]
     lib.zk_sumpoly_fold_round_evals.restype = C.c_int
+    vpp = C.POINTER(L.vp)
+    lib.zk_rounds_new.argtypes = [C.c_int, C.c_int, L.sz, L.sz, L.sz, L.vp, vpp]
+    lib.zk_rounds_free.argtypes = [L.vp]
+    lib.zk_rounds_limbs_len.argtypes = [L.vp]
+    lib.zk_rounds_limbs_len.restype = C.c_size_t
+    lib.zk_rounds_evals.argtypes = [L.vp, vpp, C.c_void_p]
+    lib.zk_rounds_fold_evals.argtypes = [L.vp, vpp, vpp, C.c_void_p]
+    lib.zk_rounds_absorb.argtypes = [L.vp, C.c_void_p]
+    lib.zk_rounds_tail.argtypes = [L.vp, vpp]
+    lib.zk_rounds_collect.argtypes = [L.vp, L.vp, u64p, u64p, u64p, u64p]
+    for name in ("zk_rounds_new", "zk_rounds_free", "zk_rounds_evals", "zk_rounds_fold_evals", "zk_rounds_absorb", "zk_rounds_tail",
+                 "zk_rounds_collect"):
+        getattr(lib, name).restype = C.c_int
     lib._sharded_declared = True
     return lib
 
@@ -83,6 +96,21 @@ class Comm:
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t, group=self.group)
         return np.stack([o.cpu().numpy().view(np.uint64) for o in out])
+
+    def all_reduce_sum_(self, t):
+        """in-place element-wise integer sum of an int64 tensor (the widened-limb exchange of the device-resident rounds,
+        include/zkmle.h zk_rounds): RCCL all-reduce directly on the device tensor, no host synchronisation; a gloo group
+        (tests, rehearsal) stages through the host"""
+        if self.world == 1:
+            return t
+        backend = self.dist.get_backend(self.group)
+        if backend == "nccl" or not t.is_cuda:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        return t
 
     def all_gather_bytes(self, data):
         """equal-length byte strings -> list of bytes, rank order"""
@@ -296,3 +324,119 @@ def g1_sum(points):
 def msm(comm, local_msm):
     """local_msm: () -> this rank's partial point (12 limbs).  One all-gather of G points, G - 1 additions."""
     return g1_sum(comm.all_gather(local_msm()))
+
+
+# ---- device-resident sharded provers: no host round trip per round (include/zkmle.h, zk_rounds) -----------------------
+class DeviceRounds:
+    """zk_rounds handle + the int64 limb buffer the ranks all-reduce.  One per sumcheck."""
+
+    def __init__(self, field, mode, nprod, nfac, nrounds, transcript, device=None):
+        import torch
+        lib = _declare_host()
+        self.field, self.mode, self.nprod, self.nfac, self.nrounds = field, mode, nprod, nfac, nrounds
+        self._t = transcript
+        h = C.c_void_p()
+        L.check(lib.zk_rounds_new(field, mode, nprod, nfac, nrounds, transcript._h, C.byref(h)))
+        self._h = h
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.limbs = torch.zeros(int(lib.zk_rounds_limbs_len(h)), dtype=torch.int64, device=dev)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and L._lib is not None:
+            L.lib().zk_rounds_free(self._h)
+            self._h = None
+
+    @staticmethod
+    def _arr(tabs):
+        flat = [p._h for p in tabs]
+        return (C.c_void_p * len(flat))(*flat)
+
+    def evals(self, tabs):
+        L.check(L.lib().zk_rounds_evals(self._h, self._arr(tabs), C.c_void_p(self.limbs.data_ptr())))
+
+    def fold_evals(self, tabs):
+        half = len(tabs[0]) // 2
+        outs = [MultilinearPolynomial.alloc(self.field, half) for _ in tabs]
+        L.check(L.lib().zk_rounds_fold_evals(self._h, self._arr(tabs), self._arr(outs), C.c_void_p(self.limbs.data_ptr())))
+        return outs
+
+    def absorb(self):
+        L.check(L.lib().zk_rounds_absorb(self._h, C.c_void_p(self.limbs.data_ptr())))
+
+    def tail(self, tabs):
+        L.check(L.lib().zk_rounds_tail(self._h, self._arr(tabs)))
+
+    def collect(self, want_final):
+        n = limbs(self.field)
+        npts = self.nfac + 1
+        claimed = np.zeros(n, np.uint64)
+        msgs = np.zeros((self.nrounds, npts, n), np.uint64)
+        chal = np.zeros((self.nrounds, n), np.uint64)
+        fin = np.zeros((self.nprod * self.nfac, n), np.uint64)
+        L.check(L.lib().zk_rounds_collect(self._h, self._t._h, L.p64(claimed), L.p64(msgs), L.p64(chal), L.p64(fin) if want_final else None))
+        return claimed, msgs, chal, fin
+
+
+def _device_rounds(comm, field, mode, tabs, nprod, nfac, transcript):
+    """shared driver: tabs = this rank's local tables (MultilinearPolynomial handles, low-bit shards).
+    -> (claimed, messages, challenges, final values (ntab, limbs))"""
+    G = comm.world
+    assert G & (G - 1) == 0, "world size must be a power of two"
+    nloc = len(tabs[0]).bit_length() - 1
+    g = G.bit_length() - 1
+    nrounds = nloc + g
+    dr = DeviceRounds(field, mode, nprod, nfac, nrounds, transcript, comm.device)
+    cur = tabs
+    if nloc >= 1:
+        dr.evals(cur)
+        comm.all_reduce_sum_(dr.limbs)                          # the round's only exchange, on the device
+        dr.absorb()
+        while len(cur[0]) >= 4:
+            cur = dr.fold_evals(cur)
+            comm.all_reduce_sum_(dr.limbs)
+            dr.absorb()
+        cur = dr.fold_evals(cur)                                # 2 entries -> 1
+    if g == 0:
+        claimed, msgs, chal, _ = dr.collect(False)
+        fin = np.stack([p.evaluated_values[0] for p in cur])
+        return claimed, msgs, chal, fin
+    # one entry per rank and table left: gather them (global index = rank) and finish replicated, in one launch
+    mine = np.stack([p.evaluated_values[0] for p in cur])       # (ntab, limbs)
+    allv = comm.all_gather(mine)                                # (G, ntab, limbs)
+    rep = [MultilinearPolynomial(field, np.ascontiguousarray(allv[:, k, :])) for k in range(len(cur))]
+    dr.evals(rep)                                               # already global: no all-reduce
+    dr.absorb()
+    dr.tail(rep)
+    return dr.collect(True)
+
+
+def sumcheck_gkr_prove_device(comm, shard, claimed_sum, transcript):
+    """sumcheck_gkr_prove with the transcript on the device: same bytes, one all-reduce per local round, one host
+    synchronisation at the gather and one at the end.  -> (coefficient rows, challenges, final table values)"""
+    field = shard.field
+    transcript.append(fe_to_bytes_be(field, claimed_sum))       # sumcheck_gkr_protocol.rs:35
+    flat = [p for prod in shard.tables for p in prod]
+    if len(flat[0]) * comm.world == 1:
+        return (np.zeros((0, shard.nfac + 1, limbs(field)), np.uint64), np.zeros((0, limbs(field)), np.uint64),
+                np.stack([p.evaluated_values[0] for p in flat]))
+    _, msgs, chal, fin = _device_rounds(comm, field, 1, flat, shard.nprod, shard.nfac, transcript)
+    return msgs, chal, fin
+
+
+def sumcheck_basic_prove_device(comm, shard, absorb_table=True):
+    """sumcheck_basic_prove with device-resident rounds.  -> (claimed_sum, round_polys, challenges)"""
+    _declare_host()
+    field = shard.field
+    G = comm.world
+    t = Transcript()
+    esz = 8 * limbs(field)
+    if absorb_table:                                            # prover.rs:38-39, global index order
+        parts = comm.all_gather_bytes(shard.to_bytes())
+        views = [np.frombuffer(p, np.uint8).reshape(-1, esz) for p in parts]
+        t.append(np.stack(views, axis=1).tobytes())
+    if len(shard) * G == 1:
+        claimed = shard.download()[0]
+        t.append(fe_to_bytes_be(field, claimed))
+        return claimed, np.zeros((0, 2, limbs(field)), np.uint64), np.zeros((0, limbs(field)), np.uint64)
+    claimed, msgs, chal, _ = _device_rounds(comm, field, 0, [shard.poly], 1, 1, t)
+    return claimed, msgs, chal
