@@ -12,6 +12,15 @@ __global__ void __launch_bounds__(256) g1_pair_add_kernel(const void *__restrict
     g1_store_xyzz(out_xyzz, k, g1_madd(g1_from_affine(g1_load_affine(in_affine, k)), g1_load_affine(in_affine, k + half)));
 }
 
+// out[k] = 2^c * in[k]: the window-shifted copies of a small base set (batched opening MSMs, zkmle_kzg.hip)
+__global__ void __launch_bounds__(256) g1_shift_kernel(const void *__restrict__ in_affine, size_t n, unsigned c, void *__restrict__ out_xyzz) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    G1Xyzz p = g1_from_affine(g1_load_affine(in_affine, k));
+    for (unsigned i = 0; i < c; i++) p = g1_dbl(p);
+    g1_store_xyzz(out_xyzz, k, p);
+}
+
 // fixed-base scalar multiplication  out[i] = [s_i] G  with a byte-window table of G
 // (table[j * 256 + v] = [v * 256^j] G, affine, 32 x 256 entries): 32 mixed adds per point
 // (compute_g1_powers_of_tau trusted_setup.rs:51-60 does one 255-bit double-and-add per point).
@@ -102,6 +111,11 @@ __global__ void __launch_bounds__(256) synthetic_bases_kernel(G1Affine g, G1Affi
 
 int launch_g1_pair_add(const void *in_affine, size_t half, void *out_xyzz, hipStream_t s) {
     g1_pair_add_kernel<<<(unsigned)((half + 255) / 256), 256, 0, s>>>(in_affine, half, out_xyzz);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int launch_g1_shift(const void *in_affine, size_t n, unsigned c, void *out_xyzz, hipStream_t s) {
+    g1_shift_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(in_affine, n, c, out_xyzz);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }

@@ -57,8 +57,10 @@ __global__ void msm_digits_kernel(const void *__restrict__ scalars, size_t n, un
 }
 
 // pass 1: per (chunk, window) histogram in LDS -> hist[(w * nchunks + chunk) * nb + b]
+// `by_chunk`: the output slot of block (w, chunk) is (chunk, w) instead of (w, chunk): every chunk is a bucket set of its
+// own that ALL windows feed (batched MSMs on window-shifted bases, zkmle_kzg.hip msm_core)
 __global__ void msm_hist_kernel(const uint16_t *__restrict__ digits, size_t n, unsigned c, unsigned nchunks,
-                                size_t chunk_len, uint32_t *__restrict__ hist) {
+                                size_t chunk_len, uint32_t *__restrict__ hist, unsigned by_chunk) {
     extern __shared__ uint32_t lds[];
     unsigned nb = 1u << (c - 1);
     unsigned chunk = blockIdx.x % nchunks, w = blockIdx.x / nchunks;
@@ -71,7 +73,8 @@ __global__ void msm_hist_kernel(const uint16_t *__restrict__ digits, size_t n, u
         if (enc) atomicAdd(&lds[digit_bucket(enc, c) - 1], 1u);
     }
     __syncthreads();
-    uint32_t *out = hist + ((size_t)w * nchunks + chunk) * nb;
+    const unsigned nwin = gridDim.x / nchunks;
+    uint32_t *out = hist + (by_chunk ? (size_t)chunk * nwin + w : (size_t)w * nchunks + chunk) * nb;
     for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) out[b] = lds[b];
 }
 
@@ -196,23 +199,27 @@ __global__ void msm_regroup_scan_kernel(const uint32_t *__restrict__ in_starts, 
 // pass 3: scatter (index | sign << 31) into bucket order, cursors staged in LDS
 __global__ void msm_scatter_kernel(const uint16_t *__restrict__ digits, size_t n, unsigned c, unsigned nchunks,
                                    size_t chunk_len, const uint32_t *__restrict__ hist,
-                                   const uint64_t *__restrict__ starts, uint32_t *__restrict__ sorted) {
+                                   const uint64_t *__restrict__ starts, uint32_t *__restrict__ sorted, unsigned by_chunk) {
     extern __shared__ uint32_t lds[];
     unsigned nb = 1u << (c - 1);
     unsigned chunk = blockIdx.x % nchunks, w = blockIdx.x / nchunks;
-    const uint32_t *off = hist + ((size_t)w * nchunks + chunk) * nb;
+    const unsigned nwin = gridDim.x / nchunks;
+    // by_chunk (see msm_hist_kernel): bucket set = chunk, fed by every window; the entry names the point of window w's
+    // shifted copy of the bases, index w * n + i
+    const uint32_t *off = hist + (by_chunk ? (size_t)chunk * nwin + w : (size_t)w * nchunks + chunk) * nb;
     for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = off[b];
     __syncthreads();
     size_t lo = (size_t)chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
     const uint16_t *d = digits + (size_t)w * n;
-    const uint64_t *st = starts + (size_t)w * nb;
+    const uint64_t *st = starts + (size_t)(by_chunk ? chunk : w) * nb;
+    const size_t base = by_chunk ? (size_t)w * n : 0;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         unsigned enc = d[i];
         if (enc) {
             unsigned b = digit_bucket(enc, c) - 1;
             uint32_t pos = atomicAdd(&lds[b], 1u);
-            unsigned neg = (enc & 0x8000u) && (w + 1 < gridDim.x / nchunks);   // the top window is never negative
-            sorted[st[b] + pos] = (uint32_t)i | (neg << 31);
+            unsigned neg = (enc & 0x8000u) && (w + 1 < nwin);                  // the top window is never negative
+            sorted[st[b] + pos] = (uint32_t)(base + i) | (neg << 31);
         }
     }
 }
@@ -346,6 +353,7 @@ int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_star
                                 unsigned group, uint32_t nout, void *out_partials, hipStream_t s);
 constexpr size_t kBaseUBytes = 128;   // one pre-converted affine point (g1u.cuh)
 int launch_g1_bases_to_u(const void *affine, size_t n, void *out_u, hipStream_t s);
+int launch_g1_shift(const void *in_affine, size_t n, unsigned c, void *out_xyzz, hipStream_t s);   // out = 2^c * in
 int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, hipStream_t s);
 int launch_msm_reduce_level(void *A, void *R, unsigned nwin, unsigned c, size_t half, hipStream_t s);
 int launch_g1_pair_add(const void *in_affine, size_t half, void *out_xyzz, hipStream_t s);

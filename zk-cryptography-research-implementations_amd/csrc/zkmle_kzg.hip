@@ -23,7 +23,14 @@ struct zk_kzg_opening_key {
     // level[t] (t = 1..nvars): 2^(nvars - t) pre-summed affine bases B^(t)_k = sum_{h < 2^t} B_{h 2^(nvars-t) + k}
     std::vector<zk_g1_bases *> level;
     size_t nvars;
+    // the levels of <= 2^kOpenBatchBits bases once more, pre-converted and padded to one stride: small_u[j][k], j = t - small_t0,
+    // so that their MSMs run as ONE batched pass (msm_core)
+    void *small_u = nullptr;      // [window][j][k] = 2^(small_c * window) B^(small_t0 + j)_k, pre-converted (msm_core, shifted)
+    unsigned small_bits = 0;      // stride = 2^small_bits points
+    size_t small_t0 = 0;          // first batched level
+    int small_c = 0;              // window size of the batched pass
 };
+constexpr unsigned kOpenBatchBits = 13;
 
 namespace {
 
@@ -67,51 +74,65 @@ int pick_window(size_t n) {
 
 int bases_u(const zk_g1_bases *b, const void **out);
 
-// sum_i [s_i] B_i ; result as XYZZ on the host
-int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c, G1Xyzz *result, zk_msm_stats *stats) {
-    const void *d_bases = nullptr;
-    ZK_TRY(bases_u(bases, &d_bases));                       // pre-converted points (cached on the handle)
-    if (c == 0) c = pick_window(n);
+// `batch` independent MSMs of n_sub terms each in ONE pass of the pipeline: sum_i [s_{j,i}] B_{j,i} for j < batch, scalars
+// stored [j][i].  Small MSMs are pure latency (a 2^12-term MSM takes ~1.6 ms of dependent launches and single-lane addition
+// chains whatever its size, plus a serial window combination), so the n MSMs of a KZG opening share one pass.
+// shifted = false (batch must be 1): the plain MSM, d_bases = the pre-converted points.
+// shifted = true: d_bases holds one copy of the points per window, [w][j][i] = 2^(c w) B_{j,i} (c must be given): every
+// window of MSM j feeds the SAME bucket set, so there are `batch` bucket sets, one reduction each and no window combination.
+// results: `batch` XYZZ points on the host.
+int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned batch, bool shifted, int c, G1Xyzz *result,
+             zk_msm_stats *stats) {
+    const size_t n = n_sub * batch;                         // digit stream: [window][j][i]
+    if (c == 0) c = pick_window(n_sub);
     if (c < 2 || c > 16) return ZK_E_ARG;
-    if (n >= ((size_t)1 << 31)) return ZK_E_ARG;            // index + sign are packed in 32 bits
-    const unsigned nwin = (256 + c - 1) / c, nb = 1u << (c - 1);
+    if (batch == 0 || (!shifted && batch != 1)) return ZK_E_ARG;
+    const unsigned nwin1 = (256 + c - 1) / c, nb = 1u << (c - 1);
+    if (n * (shifted ? nwin1 : 1) >= ((size_t)1 << 31)) return ZK_E_ARG;   // index + sign are packed in 32 bits
+    const unsigned nwin = shifted ? batch : nwin1;          // bucket sets
     const size_t nbuckets = (size_t)nwin * nb;
     // one (chunk, window) workgroup per CU-slot: long chunks make each workgroup write long runs per bucket
     // (r1: 128 chunks -> scatter 6.4 ms at 2^24; the LDS cursors hold a whole window either way)
     size_t chunk_len = (n + 15) / 16;
     if (chunk_len < 4096) chunk_len = 4096;
-    const unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
+    unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
+    if (shifted) { chunk_len = n_sub; nchunks = batch; }    // chunk j = MSM j = bucket set j
+    const unsigned by_chunk = shifted ? 1u : 0u;
     // one lane per bucket SEGMENT: cap the serial chain so that ~2^20 lanes exist whatever the window
     // size (measured r1: 2^20 terms, c = 14: 149k lanes -> 0.7e9 add/s; 521k lanes at c = 16 -> 2.1e9 add/s)
-    size_t seg_target = ((size_t)n * nwin) >> 20;
+    size_t seg_target = ((size_t)n * nwin1) >> 20;
     unsigned seg_len = (unsigned)(seg_target < 16 ? 16 : seg_target);
     Events ev;
     ZK_TRY(ev.mark());
     DevBuf digits, hist, totals, starts, seg_starts, sorted, partials, A, R;
-    ZK_TRY(digits.alloc((size_t)nwin * n * 2));
-    ZK_TRY(hist.alloc((size_t)nwin * nchunks * nb * 4));
+    ZK_TRY(digits.alloc((size_t)nwin1 * n * 2));
+    ZK_TRY(hist.alloc((size_t)nwin1 * nchunks * nb * 4));
     ZK_TRY(totals.alloc(nbuckets * 4));
     ZK_TRY(starts.alloc((nbuckets + 1) * 8));
     ZK_TRY(seg_starts.alloc((nbuckets + 2) * 4));
-    msm_digits_kernel<<<grid_for(n), kBlock>>>(d_scalars, n, (unsigned)c, nwin, (uint16_t *)digits.p);
+    msm_digits_kernel<<<grid_for(n), kBlock>>>(d_scalars, n, (unsigned)c, nwin1, (uint16_t *)digits.p);
     ZK_HIP(hipGetLastError());
     ZK_TRY(ev.mark());
     // counting sort, bucket counters staged in LDS
     size_t lds_bytes = (size_t)nb * 4;
     ZK_HIP(hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     ZK_HIP(hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    msm_hist_kernel<<<nwin * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len, (uint32_t *)hist.p);
-    msm_chunk_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock>>>((uint32_t *)hist.p, nwin, nchunks, nb, (uint32_t *)totals.p);
+    msm_hist_kernel<<<nwin1 * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len, (uint32_t *)hist.p,
+                                                                 by_chunk);
+    // per bucket set: exclusive prefix over the blocks that feed it (chunks of a window; or, shifted, the windows of a chunk)
+    msm_chunk_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock>>>((uint32_t *)hist.p, nwin, shifted ? nwin1 : nchunks, nb,
+                                                                                    (uint32_t *)totals.p);
+    const uint32_t *d_totals = (const uint32_t *)totals.p;
     {
         unsigned ntiles = (unsigned)((nbuckets + kScanTile - 1) / kScanTile);
         DevBuf te, ts, tm;
         ZK_TRY(te.alloc((size_t)ntiles * 8));
         ZK_TRY(ts.alloc((size_t)ntiles * 4));
         ZK_TRY(tm.alloc((size_t)ntiles * 4));
-        msm_scan_tiles_kernel<<<ntiles, kScanTile>>>((const uint32_t *)totals.p, nbuckets, seg_len, (uint64_t *)te.p, (uint32_t *)ts.p, (uint32_t *)tm.p);
+        msm_scan_tiles_kernel<<<ntiles, kScanTile>>>(d_totals, nbuckets, seg_len, (uint64_t *)te.p, (uint32_t *)ts.p, (uint32_t *)tm.p);
         msm_scan_tile_totals_kernel<<<1, 64>>>((uint64_t *)te.p, (uint32_t *)ts.p, (const uint32_t *)tm.p, ntiles, nbuckets,
                                               (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
-        msm_scan_apply_kernel<<<ntiles, kScanTile>>>((const uint32_t *)totals.p, nbuckets, seg_len, (const uint64_t *)te.p, (const uint32_t *)ts.p,
+        msm_scan_apply_kernel<<<ntiles, kScanTile>>>(d_totals, nbuckets, seg_len, (const uint64_t *)te.p, (const uint32_t *)ts.p,
                                                      (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipDeviceSynchronize());
@@ -122,7 +143,7 @@ int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c,
     ZK_HIP(hipMemcpy(tail, (uint32_t *)seg_starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
     uint32_t nseg = tail[0], max_segs = tail[1];
     ZK_TRY(sorted.alloc((entries ? entries : 1) * 4));
-    if (c >= 12 && n >= ((size_t)1 << 22)) {   // measured r1: wins at 2^24 (8.6 -> 5.4 ms), loses below 2^21
+    if (!shifted && c >= 12 && n >= ((size_t)1 << 22)) {   // measured r1: wins at 2^24 (8.6 -> 5.4 ms), loses below 2^21
         // two-level scatter: partition by the high bits of the bucket id (tile-sorted whole-run writes), then finish
         // each 256-bucket partition with one workgroup (msm_kernels.cuh)
         const unsigned lb = (unsigned)(c - 1) < kFineBits ? (unsigned)(c - 1) : kFineBits, nh = 1u << (c - 1 - lb);
@@ -144,8 +165,9 @@ int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c,
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipDeviceSynchronize());      // the intermediates are freed on scope exit
     } else {
-        msm_scatter_kernel<<<nwin * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len,
-                                                                       (const uint32_t *)hist.p, (const uint64_t *)starts.p, (uint32_t *)sorted.p);
+        msm_scatter_kernel<<<nwin1 * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len,
+                                                                        (const uint32_t *)hist.p, (const uint64_t *)starts.p, (uint32_t *)sorted.p,
+                                                                        by_chunk);
         ZK_HIP(hipGetLastError());
     }
     ZK_TRY(ev.mark());
@@ -192,16 +214,19 @@ int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c,
         ZK_HIP(hipMemcpyAsync(&sums[w], (char *)R.p + ((size_t)w << c) * sizeof(G1Xyzz), sizeof(G1Xyzz), hipMemcpyDeviceToHost, nullptr));
     ZK_TRY(ev.mark());
     ZK_HIP(hipDeviceSynchronize());
-    // window combination (host, W points): acc = 2^c * acc + S_w from the top window down
-    G1Xyzz acc = g1_xyzz_inf();
-    for (int w = (int)nwin - 1; w >= 0; w--) {
-        for (int k = 0; k < c; k++) acc = g1_dbl(acc);
-        acc = g1_add(acc, sums[w]);
+    if (shifted) {                                          // the shifts live in the bases: bucket set j IS MSM j
+        for (unsigned j = 0; j < batch; j++) result[j] = sums[j];
+    } else {                                                // window combination (host, W points): acc = 2^c * acc + S_w
+        G1Xyzz acc = g1_xyzz_inf();
+        for (int w = (int)nwin1 - 1; w >= 0; w--) {
+            for (int k = 0; k < c; k++) acc = g1_dbl(acc);
+            acc = g1_add(acc, sums[w]);
+        }
+        result[0] = acc;
     }
-    *result = acc;
     if (stats) {
         stats->window_bits = c;
-        stats->windows = (int)nwin;
+        stats->windows = (int)nwin1;
         stats->terms = n;
         stats->entries = entries;
         stats->segments = nseg;
@@ -212,6 +237,13 @@ int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c,
         stats->ms_total = ev.ms(0, 4);
     }
     return ZK_OK;
+}
+
+// sum_i [s_i] B_i ; result as XYZZ on the host
+int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c, G1Xyzz *result, zk_msm_stats *stats) {
+    const void *d_bases = nullptr;
+    ZK_TRY(bases_u(bases, &d_bases));                       // pre-converted points (cached on the handle)
+    return msm_core(d_scalars, d_bases, n, 1, false, c, result, stats);
 }
 
 int bases_alloc(size_t n, zk_g1_bases **out) {
@@ -416,12 +448,37 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
         rc = normalize_to_bases(xyzz.p, half, &key->level[t]);
         cur = key->level[t];
     }
+    if (rc == ZK_OK && key->nvars >= 2) {                   // with one variable there is a single 1-term MSM: nothing to batch
+        key->small_bits = (unsigned)(key->nvars - 1 < kOpenBatchBits ? key->nvars - 1 : kOpenBatchBits);
+        key->small_t0 = key->nvars - key->small_bits;
+        const size_t stride = (size_t)1 << key->small_bits, nlev = key->small_bits + 1, total = nlev * stride;
+        key->small_c = pick_window(stride);
+        const unsigned c = (unsigned)key->small_c, nwin = (256 + c - 1) / c;
+        DevBuf aff, xyzz;                                   // the levels side by side (padding = infinity), then shifted window by window
+        rc = aff.alloc(total * sizeof(G1Affine));
+        if (rc == ZK_OK) rc = xyzz.alloc(total * sizeof(G1Xyzz));
+        hipError_t e = hipSuccess;
+        if (rc == ZK_OK) e = hipMalloc(&key->small_u, (size_t)nwin * total * kBaseUBytes);
+        if (rc == ZK_OK && e == hipSuccess) e = hipMemsetAsync(aff.p, 0, total * sizeof(G1Affine), nullptr);
+        for (size_t j = 0; j < nlev && rc == ZK_OK && e == hipSuccess; j++) {
+            const zk_g1_bases *lv = key->level[key->small_t0 + j];
+            e = hipMemcpyAsync((char *)aff.p + j * stride * sizeof(G1Affine), lv->dptr, lv->n * sizeof(G1Affine), hipMemcpyDeviceToDevice, nullptr);
+        }
+        if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
+        for (unsigned w = 0; w < nwin && rc == ZK_OK; w++) {
+            rc = launch_g1_bases_to_u(aff.p, total, (char *)key->small_u + (size_t)w * total * kBaseUBytes, nullptr);
+            if (rc == ZK_OK && w + 1 < nwin) rc = launch_g1_shift(aff.p, total, c, xyzz.p, nullptr);
+            if (rc == ZK_OK && w + 1 < nwin) rc = launch_batch_to_affine(xyzz.p, total, aff.p, nullptr);
+        }
+        if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = ZK_E_HIP;
+    }
     if (rc != ZK_OK) { zk_kzg_opening_key_free(key.release()); return rc; }
     *out = key.release();
     return ZK_OK;
 }
 int zk_kzg_opening_key_free(zk_kzg_opening_key *k) {
     if (!k) return ZK_OK;
+    if (k->small_u) (void)hipFree(k->small_u);
     for (zk_g1_bases *b : k->level) zk_g1_bases_free(b);
     delete k;
     return ZK_OK;
@@ -449,21 +506,39 @@ int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg
     if (rc == ZK_OK) rc = zk_mle_sub_scalar(poly, evaluation, sub, nullptr);                    // :74-80
     if (rc == ZK_OK && poly->len >= 2) rc = zk_table_alloc(ZK_FR381, poly->len / 2, &nxt);
     if (rc == ZK_OK && poly->len >= 2) rc = zk_table_alloc(ZK_FR381, poly->len / 2, &q);
+    // quotients of the batched (small) levels are collected, zero-padded, in one scalar buffer [j][2^small_bits]
+    const bool batched = key->small_u != nullptr && rc == ZK_OK;
+    const size_t stride = (size_t)1 << key->small_bits, nlev = key->small_bits + 1;
+    DevBuf smallq;
+    if (batched) {
+        rc = smallq.alloc(nlev * stride * 32);
+        if (rc == ZK_OK && hipMemsetAsync(smallq.p, 0, nlev * stride * 32, nullptr) != hipSuccess) rc = ZK_E_HIP;
+    }
     for (size_t i = 0; i < nopen && rc == ZK_OK; i++) {                                          // :86
         size_t half = sub->len / 2;
+        const size_t t = i + 1;
+        const bool small = batched && t >= key->small_t0;
+        void *qdst = small ? (void *)((char *)smallq.p + (t - key->small_t0) * stride * 32) : q->dptr;
         // quotient = hi half - lo half (compute_quotient_polynomial :165-179)
-        elementwise_kernel<Fr381, OP_HI_MINUS_LO><<<grid_for(half), kBlock>>>(sub->dptr, nullptr, q->dptr, half, fe_zero<Fr381>());
+        elementwise_kernel<Fr381, OP_HI_MINUS_LO><<<grid_for(half), kBlock>>>(sub->dptr, nullptr, qdst, half, fe_zero<Fr381>());
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; break; }
-        q->len = half;
-        // proof_i = sum_j [blown_up(q)[j]] B_j  (:96-107)  ==  sum_k [q[k]] B^(i+1)_k
-        G1Xyzz pi;
-        rc = msm_device(q->dptr, key->level[i + 1], half, 0, &pi, nullptr);
-        if (rc != ZK_OK) break;
-        affine_to_u64(g1_to_affine(pi), proofs + 12 * i);
+        if (!small) {
+            q->len = half;
+            // proof_i = sum_j [blown_up(q)[j]] B_j  (:96-107)  ==  sum_k [q[k]] B^(i+1)_k
+            G1Xyzz pi;
+            rc = msm_device(q->dptr, key->level[t], half, 0, &pi, nullptr);
+            if (rc != ZK_OK) break;
+            affine_to_u64(g1_to_affine(pi), proofs + 12 * i);
+        }
         nxt->len = half;
         rc = zk_mle_fold(sub, 0, opening + 4 * i, nxt, nullptr);                                 // :113-119
-        zk_table *t = sub; sub = nxt; nxt = t;
+        zk_table *tt = sub; sub = nxt; nxt = tt;
+    }
+    if (batched && rc == ZK_OK) {                           // the small levels' proofs: one batched pass
+        std::vector<G1Xyzz> pis(nlev);
+        rc = msm_core(smallq.p, key->small_u, stride, (unsigned)nlev, true, key->small_c, pis.data(), nullptr);
+        for (size_t j = 0; j < nlev && rc == ZK_OK; j++) affine_to_u64(g1_to_affine(pis[j]), proofs + 12 * (key->small_t0 + j - 1));
     }
     zk_table_free(sub);
     zk_table_free(nxt);
