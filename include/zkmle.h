@@ -291,6 +291,30 @@ int zk_gkr_prove_succinct(const zk_gate *gates, const size_t *gate_counts, size_
                           uint64_t *rb_evaluation, uint64_t *rb_proofs, uint64_t *rc_evaluation,
                           uint64_t *rc_proofs);
 
+/* ---- verifier side of multilinear KZG: G2, pairings (HOST code: O(n) work on n + 2 points, csrc/pairing.h) ------------
+ * G2 points: affine over Fq2, 24 limbs = x.c0, x.c1, y.c0, y.c1 (6 x u64 Montgomery each), all zero = infinity.
+ * GT elements: 72 limbs = the Fq2 coefficients of w^0 .. w^5 in Fq12 = Fq2[w]/(w^6 - (1 + u)), (c0, c1) each. */
+int zk_g2_generator(uint64_t *out24);
+int zk_g2_is_on_curve(const uint64_t *p24);                                 /* 1 / 0 */
+int zk_g2_add(const uint64_t *p24, const uint64_t *q24, uint64_t *out24);
+int zk_g2_mul_fr(const uint64_t *p24, const uint64_t *scalar_fr, uint64_t *out24);          /* mul_bigint(into_bigint) */
+int zk_pairing(const uint64_t *g1_12, const uint64_t *g2_24, uint64_t *gt72);               /* P::pairing */
+int zk_pairing_product_is_one(const uint64_t *g1s, const uint64_t *g2s, size_t n, int *ok);
+/* compute_g2_powers_of_tau  trusted_setup.rs:62-72 : out[i] = [tau_i] G2 (ntaus x 24 limbs) */
+int zk_kzg_setup_g2(const uint64_t *taus, size_t ntaus, uint64_t *out);
+/* MultilinearKZG::verify  multilinear_kzg.rs:131-158 ; *ok = 1 / 0.  nopen != nproofs -> ZK_E_KZG_LEN (:137-141), as is
+ * ng2 > nproofs (the reference indexes proofs[i] for every G2 power, :149-154) */
+int zk_kzg_verify(const uint64_t *commitment12, const uint64_t *opening_values, size_t nopen, const uint64_t *evaluation,
+                  const uint64_t *proofs, size_t nproofs, const uint64_t *g2_powers, size_t ng2, int *ok);
+
+/* verify_succinct  gkr/src/succinct_gkr_protocol.rs:172-285 (BLS12-381 Fr): GKR verification without the inputs, then the
+ * two KZG openings of the committed input polynomial at the last layer's challenges */
+int zk_gkr_verify_succinct(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *circuit_output,
+                           size_t output_len, const uint64_t *layer_claims, const uint64_t *coeffs, const uint64_t *wb_evals,
+                           const uint64_t *wc_evals, const uint64_t *commitment12, const uint64_t *rb_evaluation,
+                           const uint64_t *rb_proofs, size_t n_rb_proofs, const uint64_t *rc_evaluation, const uint64_t *rc_proofs,
+                           size_t n_rc_proofs, const uint64_t *g2_powers, size_t ng2, int *ok);
+
 /* ---- sparse (linear-time) GKR prover: the generalisation BASELINE config 4 needs -------------------------
  * The reference materialises dense wiring predicates add_i / mul_i of 2^(3i+2) entries and a dense f(b,c) of
  * 2^(2i+2) entries (arithmetic_circuit.rs:126-163, utils.rs:8-21) and ties a layer's width to its index

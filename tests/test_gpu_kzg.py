@@ -63,6 +63,10 @@ def test_setup_commit_open_reference_cases(zk, ref_kats, derived_kats):
             assert O.g1_affine_ints(commitment) == (int(d["commit_x"], 16), int(d["commit_y"], 16))
         # commitment == [f(tau)] G  (what the pairing check states when tau is known)
         assert O.g1_affine_ints(commitment) == M.g1_mul(M.G1, d["f_tau"] % R)
+        # ... and the pairing check itself: MultilinearKZG::verify, the reference's own round trip (:216-303)
+        assert zk.MultilinearKZG.verify(setup, commitment, opening, proof) is True
+        wrong = zk.MultilinearKZGProof(zk.from_ints(0, [(d["f_open"] + 1) % R])[0], proof.proofs)
+        assert zk.MultilinearKZG.verify(setup, commitment, opening, wrong) is False
 
 
 def test_kzg_length_asserts(zk):
@@ -178,6 +182,11 @@ def test_commit_open_n16(zk):
     for i in range(nv):
         acc = O.g1_add(acc, O.g1_mul_fr(proof.proofs[i], O.from_ints(O.FR381, [(taus_i[i] - opening_i[i]) % R])[0]))
     assert O.g1_affine_ints(acc) == M.g1_mul(M.G1, (f_tau - v) % R)
+    # 17 pairings against the G2 powers (host): accepts the proof, rejects a swapped pair of quotient commitments
+    assert zk.MultilinearKZG.verify(setup, c, opening, proof) is True
+    swapped = proof.proofs.copy()
+    swapped[[0, 1]] = swapped[[1, 0]]
+    assert zk.MultilinearKZG.verify(setup, c, opening, zk.MultilinearKZGProof(proof.evaluation, swapped)) is False
 
 
 def test_commit_open_random_n10(zk):

@@ -51,6 +51,12 @@ def test_prove_succinct_reference_circuits(ref_kats):
         assert np.array_equal(proof.input_polynomial_commitment, want["input_polynomial_commitment"])
         for got, (ev, prs) in ((proof.input_rb_proof, want["input_rb_proof"]), (proof.input_rc_proof, want["input_rc_proof"])):
             assert np.array_equal(got.evaluation, ev) and np.array_equal(got.proofs, prs)
+        # verify_succinct (succinct_gkr_protocol.rs:172-285, the reference's own round trip :295-360): GKR rounds + 2 KZG verifications
+        assert zk.gkr.verify_succinct(circuit, proof, setup) is True
+        bad = zk.MultilinearKZGProof(proof.input_rb_proof.evaluation, proof.input_rb_proof.proofs[::-1].copy())
+        tampered = zk.gkr.SuccinctProof(proof, proof.input_polynomial_commitment, bad, proof.input_rc_proof)
+        if len(bad.proofs) > 1 and not np.array_equal(bad.proofs, proof.input_rb_proof.proofs):
+            assert zk.gkr.verify_succinct(circuit, tampered, setup) is False
         # the opened values are the verifier's wb / wc of the input layer (succinct_gkr_protocol.rs:226-233)
         ch = want["challenges"][-O.gkr_rounds(len(layers) - 1):]
         assert np.array_equal(proof.input_rb_proof.evaluation, O.evaluate(O.FR381, inputs, ch[: len(ch) // 2]))

@@ -17,7 +17,7 @@ from .sumcheck import Transcript, ProductPolynomial, SumPolynomial, Prover, Veri
 from . import gkr  # noqa: F401
 from .gkr import Circuit, Gate, Layer, Operator  # noqa: F401
 from . import kzg  # noqa: F401
-from .kzg import G1Bases, TrustedSetup, MultilinearKZG  # noqa: F401
+from .kzg import G1Bases, TrustedSetup, MultilinearKZG, MultilinearKZGProof  # noqa: F401
 from . import sharded  # noqa: F401
 
 __all__ = ["MultilinearPolynomial", "FR381", "FQ381", "BN254_FQ", "BN254_FR", "ZkError", "ReferencePanic",

@@ -224,8 +224,11 @@ template <class F> int gkr_prove(const zk_gate *gates, const size_t *gate_counts
 
 template <class F> int gkr_verify(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *inputs, size_t ninputs,
                                   const uint64_t *circuit_output, size_t output_len, const uint64_t *layer_claims, const uint64_t *coeffs,
-                                  const uint64_t *wb_evals, const uint64_t *wc_evals, int *ok) {
+                                  const uint64_t *wb_evals, const uint64_t *wc_evals, int *ok, uint64_t *last_challenges = nullptr) {
+    // inputs == nullptr: verify_succinct (succinct_gkr_protocol.rs:172-285) -- the input layer is not evaluated here; its two
+    // openings are checked by the caller against the commitment, at the last layer's challenges returned in last_challenges
     const size_t L64 = F::N / 2;
+    const bool succinct = inputs == nullptr;
     *ok = 0;
     zk_transcript tr;
     std::vector<uint64_t> w0(circuit_output, circuit_output + output_len * L64);      // :153-159
@@ -254,21 +257,27 @@ template <class F> int gkr_verify(const zk_gate *gates, const size_t *gate_count
         if (L + 1 < nlayers) {                                                       // :183-187
             memcpy(wbe, wb_evals + L * L64, L64 * 8);
             memcpy(wce, wc_evals + L * L64, L64 * 8);
+        } else if (succinct) {                                                       // succinct_gkr_protocol.rs:214-215: zero
+            memset(wbe, 0, sizeof wbe);
+            memset(wce, 0, sizeof wce);
+            if (last_challenges) memcpy(last_challenges, ch.data(), rounds * L64 * 8);
         } else {                                                                     // :188-194 the verifier's own inputs
             TablePtr in;
             ZK_TRY(upload_table(F::ID, inputs, ninputs, in));
             ZK_TRY(zk_mle_evaluate(in.get(), ch.data(), mid, wbe));
             ZK_TRY(zk_mle_evaluate(in.get(), ch.data() + mid * L64, rounds - mid, wce));
         }
-        TablePtr add_bc, mul_bc;
-        size_t k = prev.size() / L64 / 2;
-        ZK_TRY((derive_bc<F>(gates + goff, gate_counts[L], L, ra, alpha, beta, prev.data(), prev.data() + k * L64, k, add_bc, mul_bc)));   // utils.rs:84-135
-        uint64_t ar[6], mr[6];
-        ZK_TRY(zk_mle_evaluate(add_bc.get(), ch.data(), rounds, ar));
-        ZK_TRY(zk_mle_evaluate(mul_bc.get(), ch.data(), rounds, mr));
         Fe<F> wb = load_el<F>(wbe), wc = load_el<F>(wce);
-        Fe<F> expect = fe_add<F>(fe_mul<F>(load_el<F>(ar), fe_add<F>(wb, wc)), fe_mul<F>(load_el<F>(mr), fe_mul<F>(wb, wc)));
-        if (!fe_eq<F>(expect, load_el<F>(last))) return ZK_OK;                       // :221-223
+        if (!(succinct && L + 1 == nlayers)) {                                       // the succinct verifier skips this for the input layer (:217)
+            TablePtr add_bc, mul_bc;
+            size_t k = prev.size() / L64 / 2;
+            ZK_TRY((derive_bc<F>(gates + goff, gate_counts[L], L, ra, alpha, beta, prev.data(), prev.data() + k * L64, k, add_bc, mul_bc)));   // utils.rs:84-135
+            uint64_t ar[6], mr[6];
+            ZK_TRY(zk_mle_evaluate(add_bc.get(), ch.data(), rounds, ar));
+            ZK_TRY(zk_mle_evaluate(mul_bc.get(), ch.data(), rounds, mr));
+            Fe<F> expect = fe_add<F>(fe_mul<F>(load_el<F>(ar), fe_add<F>(wb, wc)), fe_mul<F>(load_el<F>(mr), fe_mul<F>(wb, wc)));
+            if (!fe_eq<F>(expect, load_el<F>(last))) return ZK_OK;                   // :221-223
+        }
         prev = ch;                                                                   // :225
         tr.t.append_be<F>(wb);                                                       // :227
         Fe<F> a = tr.t.random_challenge_as_field_element<F>();
@@ -341,6 +350,29 @@ int zk_gkr_verify(int field, const zk_gate *gates, const size_t *gate_counts, si
     ZK_TRY(require_device());
     ZK_DISPATCH_FIELD(field, return gkr_verify<F>(gates, gate_counts, nlayers, inputs, ninputs, circuit_output, output_len, layer_claims,
                                                   coeffs, wb_evals, wc_evals, ok));
+    return ZK_OK;
+}
+
+// verify_succinct  gkr/src/succinct_gkr_protocol.rs:172-285 (BLS12-381 Fr): the GKR rounds as above without the input
+// layer, then MultilinearKZG::verify of the two input openings at the last layer's challenges (:262-283)
+int zk_gkr_verify_succinct(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, const uint64_t *circuit_output, size_t output_len,
+                           const uint64_t *layer_claims, const uint64_t *coeffs, const uint64_t *wb_evals, const uint64_t *wc_evals,
+                           const uint64_t *commitment12, const uint64_t *rb_evaluation, const uint64_t *rb_proofs, size_t n_rb_proofs,
+                           const uint64_t *rc_evaluation, const uint64_t *rc_proofs, size_t n_rc_proofs, const uint64_t *g2_powers, size_t ng2,
+                           int *ok) {
+    if (!gates || !gate_counts || !circuit_output || !layer_claims || !coeffs || !commitment12 || !rb_evaluation || !rc_evaluation || !ok ||
+        nlayers == 0)
+        return ZK_E_ARG;
+    ZK_TRY(require_device());
+    size_t rounds = zk_gkr_rounds(nlayers - 1), mid = rounds / 2;
+    std::vector<uint64_t> ch(rounds * 4);
+    ZK_TRY((gkr_verify<Fr381>(gates, gate_counts, nlayers, nullptr, 0, circuit_output, output_len, layer_claims, coeffs, wb_evals, wc_evals, ok,
+                              ch.data())));
+    if (!*ok) return ZK_OK;
+    int okb = 0, okc = 0;
+    ZK_TRY(zk_kzg_verify(commitment12, ch.data(), mid, rb_evaluation, rb_proofs, n_rb_proofs, g2_powers, ng2, &okb));                    // :266-271
+    ZK_TRY(zk_kzg_verify(commitment12, ch.data() + mid * 4, rounds - mid, rc_evaluation, rc_proofs, n_rc_proofs, g2_powers, ng2, &okc));   // :272-277
+    *ok = (okb && okc) ? 1 : 0;
     return ZK_OK;
 }
 

@@ -221,6 +221,36 @@ def prove_succinct(circuit, inputs, trusted_setup):
     return SuccinctProof(base, commit, MultilinearKZGProof(rb_ev, rb_pr), MultilinearKZGProof(rc_ev, rc_pr))
 
 
+def verify_succinct(circuit, proof, trusted_setup):
+    """succinct_gkr_protocol::verify_succinct :172-285"""
+    lib = _decl()
+    if not getattr(lib, "_succ_verify_declared", False):
+        u64p, sz, gp, szp = L.u64p, L.sz, C.POINTER(_Gate), C.POINTER(C.c_size_t)
+        lib.zk_gkr_verify_succinct.argtypes = [gp, szp, sz, u64p, sz, u64p, u64p, u64p, u64p, u64p, u64p, u64p, sz, u64p, u64p, sz, u64p, sz,
+                                               C.POINTER(C.c_int)]
+        lib.zk_gkr_verify_succinct.restype = C.c_int
+        lib._succ_verify_declared = True
+    if circuit.field != L.FR381:
+        raise L.ZkError(L.ZK_E_ARG, "verify_succinct needs the pairing's scalar field (BLS12-381 Fr)")
+    gates, counts = circuit._flat()
+    nl = len(circuit.layers)
+    claims = np.ascontiguousarray(np.stack([p.claimed_sum for p in proof.sumcheck_proofs]), np.uint64)
+    co = np.ascontiguousarray(np.concatenate([p.round_univariate_polynomials for p in proof.sumcheck_proofs]), np.uint64)
+    pad = lambda a, w: np.ascontiguousarray(a, np.uint64) if len(a) else np.zeros((1, w), np.uint64)
+    wb, wc = pad(proof.wb_evaluations, 4), pad(proof.wc_evaluations, 4)
+    outp = np.ascontiguousarray(proof.circuit_output, np.uint64)
+    rb, rc = proof.input_rb_proof, proof.input_rc_proof
+    rbp, rcp = pad(rb.proofs, 12), pad(rc.proofs, 12)
+    g2 = trusted_setup.g2_powers_of_tau
+    ok = C.c_int(0)
+    L.check(lib.zk_gkr_verify_succinct(gates, counts, nl, L.p64(outp), outp.shape[0], L.p64(claims), L.p64(co), L.p64(wb), L.p64(wc),
+                                       L.p64(np.ascontiguousarray(proof.input_polynomial_commitment, np.uint64)),
+                                       L.p64(np.ascontiguousarray(rb.evaluation, np.uint64)), L.p64(rbp), len(rb.proofs),
+                                       L.p64(np.ascontiguousarray(rc.evaluation, np.uint64)), L.p64(rcp), len(rc.proofs),
+                                       L.p64(g2), g2.shape[0], C.byref(ok)))
+    return bool(ok.value)
+
+
 # ---- sparse (linear-time) GKR: layers are gate lists with their own widths (include/zkmle.h) -----------------
 def _decl_sparse():
     lib = _decl()

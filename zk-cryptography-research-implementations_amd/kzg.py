@@ -31,6 +31,10 @@ def _decl():
         "zk_kzg_commit": [vp, vp, u64p],
         "zk_kzg_opening_key_new": [vp, C.POINTER(vp)], "zk_kzg_opening_key_free": [vp],
         "zk_kzg_open": [vp, vp, vp, u64p, sz, sz, u64p, u64p],
+        "zk_g2_generator": [u64p], "zk_g2_is_on_curve": [u64p], "zk_g2_add": [u64p, u64p, u64p], "zk_g2_mul_fr": [u64p, u64p, u64p],
+        "zk_pairing": [u64p, u64p, u64p], "zk_pairing_product_is_one": [u64p, u64p, sz, C.POINTER(C.c_int)],
+        "zk_kzg_setup_g2": [u64p, sz, u64p],
+        "zk_kzg_verify": [u64p, u64p, sz, u64p, u64p, sz, u64p, sz, C.POINTER(C.c_int)],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -103,11 +107,14 @@ def compute_lagrange_basis(taus):
 
 
 class TrustedSetup:
-    """trusted_setup.rs:5-22 (G1 side; the G2 powers are pairing-side, out of scope: only their count is kept)"""
+    """trusted_setup.rs:5-22.  g1_powers_of_tau live in HBM (a G1Bases handle); g2_powers_of_tau ([tau_i] G2, n x 24 limbs,
+    :62-72) are verifier-side host data, computed on first use."""
 
-    def __init__(self, g1_powers_of_tau, n_g2):
+    def __init__(self, g1_powers_of_tau, n_g2, taus=None):
         self.g1_powers_of_tau = g1_powers_of_tau
         self.n_g2_powers_of_tau = n_g2
+        self._taus = taus
+        self._g2 = None
         self._opening_key = None
 
     @classmethod
@@ -115,7 +122,17 @@ class TrustedSetup:
         t = np.ascontiguousarray(taus, np.uint64).reshape(-1, 4)
         h = C.c_void_p()
         L.check(_decl().zk_kzg_setup_g1(L.p64(t), t.shape[0], C.byref(h)))
-        return cls(G1Bases(_handle=h), t.shape[0])
+        return cls(G1Bases(_handle=h), t.shape[0], t.copy())
+
+    @property
+    def g2_powers_of_tau(self):
+        if self._g2 is None:
+            if self._taus is None:
+                raise L.ZkError(L.ZK_E_ARG, "this setup was built without the taus: no G2 powers")
+            out = np.zeros((self._taus.shape[0], 24), np.uint64)
+            L.check(_decl().zk_kzg_setup_g2(L.p64(self._taus), self._taus.shape[0], L.p64(out)))
+            self._g2 = out
+        return self._g2
 
     def opening_key(self):
         if self._opening_key is None:
@@ -158,3 +175,15 @@ class MultilinearKZG:
         L.check(_decl().zk_kzg_open(polynomial._h, trusted_setup.g1_powers_of_tau._h, key, optr, o.shape[0],
                                     trusted_setup.n_g2_powers_of_tau, L.p64(ev), L.p64(proofs)))
         return MultilinearKZGProof(ev, proofs[: o.shape[0]])
+
+    @staticmethod
+    def verify(trusted_setup, commitment, opening_values, proof):    # :131-158 (pairings on the host, csrc/pairing.h)
+        o = np.ascontiguousarray(opening_values, np.uint64).reshape(-1, 4)
+        prs = np.ascontiguousarray(proof.proofs, np.uint64).reshape(-1, 12)
+        g2 = trusted_setup.g2_powers_of_tau
+        ok = C.c_int(0)
+        dummy = np.zeros(24, np.uint64)
+        L.check(_decl().zk_kzg_verify(L.p64(np.ascontiguousarray(commitment, np.uint64)), L.p64(o) if o.size else L.p64(dummy), o.shape[0],
+                                      L.p64(np.ascontiguousarray(proof.evaluation, np.uint64)), L.p64(prs) if prs.size else L.p64(dummy),
+                                      prs.shape[0], L.p64(g2), g2.shape[0], C.byref(ok)))
+        return bool(ok.value)
