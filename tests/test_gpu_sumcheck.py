@@ -150,7 +150,8 @@ def test_gkr_round_univariate_and_roundtrip(zk, ref_kats, derived_kats):
 
 
 @pytest.mark.parametrize("field", [0, 2])
-@pytest.mark.parametrize("shape", [(2, 2, 1), (2, 2, 2), (2, 2, 5), (2, 2, 11), (3, 2, 6), (2, 3, 6), (1, 2, 4), (4, 3, 3), (2, 1, 4)])
+@pytest.mark.parametrize("shape", [(2, 2, 1), (2, 2, 2), (2, 2, 5), (2, 2, 11), (3, 2, 6), (2, 3, 6), (1, 2, 4), (4, 3, 3), (2, 1, 4),
+                                   (3, 2, 13), (2, 3, 12), (8, 2, 12)])   # > 2^11 entries: producer + finish kernels before the tail
 def test_gkr_sumcheck_random_vs_oracle(zk, field, shape):
     nprod, nfac, logn = shape
     n = 1 << logn
@@ -223,3 +224,23 @@ def test_device_transcript_any_sponge_fill(zk, field):
         assert t_gpu.sample_random_challenge() == t_cpu.sample_random_challenge(), plen
     st = zk.sumcheck.last_stats()
     assert st["rounds"] == 3 and st["ms_rounds"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,logn", [(1, 13), (3, 12)])
+def test_sumcheck_provers_other_fields_beyond_the_tail(zk, field, logn):
+    """12-limb (BLS12-381 Fq) and BN254 Fr tables larger than the tail kernel's 2^11 entries: the two-launch rounds
+    (fold_round_evals / fold_half_sums + sumcheck_finish_kernel) and the hand-over to the tail, against the oracle"""
+    n = 1 << logn
+    tabs = np.stack([np.stack([rand_table(zk, field, n, 700 + 2 * p + f) for f in range(2)]) for p in range(2)])
+    sp = mk_sum(zk, field, tabs)
+    claimed = O.vec_sum(field, O.sumpoly_reduce(field, tabs))
+    t_gpu, t_cpu = zk.Transcript(), O.Transcript()
+    result = zk.sumcheck.prove(sp, claimed, t_gpu)
+    co, ch = O.sumcheck_gkr_prove(field, tabs, claimed, t_cpu)
+    assert np.array_equal(result.round_univariate_polynomials, co) and np.array_equal(result.random_challenges, ch)
+    assert t_gpu.sample_random_challenge() == t_cpu.sample_random_challenge()
+    table = tabs[0, 0]
+    proof = zk.Prover.init(field, zk.MultilinearPolynomial(field, table)).prove()
+    cs, rp, _ = O.sumcheck_basic_prove(field, table)
+    assert np.array_equal(proof.initial_claimed_sum, cs) and np.array_equal(proof.round_univariate_polynomials, rp)
