@@ -31,7 +31,7 @@ def test_transcript_matches_oracle_on_random_schedules(zk):
         a, b = zk.Transcript(), O.Transcript()
         for step in range(40):
             if rng.random() < 0.6:
-                data = bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 31, 32, 96, 135, 136, 137, 300])))
+                data = bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 31, 32, 96, 135, 136, 137, 300, 1000, 4103])))
                 a.append(data)
                 b.append(data)
             elif rng.random() < 0.5:

@@ -54,6 +54,12 @@ struct zk_table {
 };
 
 namespace zk {
+class Transcript;
+// transcript.append(convert_to_bytes(table)) (evaluation_form.rs:35-43, prover.rs:38-39): the GPU converts Montgomery ->
+// canonical big-endian chunk by chunk into pinned host buffers while the host hashes the previous chunk (zkmle_sumcheck.hip)
+int transcript_absorb_table(Transcript &t, const zk_table *table);
+// two pinned host staging buffers of at least `bytes` each, owned per device
+int pinned_pair(size_t bytes, void *out[2]);
 // a temporary table backed by the caching pool (internal provers: dozens of same-sized temporaries per proof)
 int table_alloc_pooled(int field, size_t len, zk_table **out);
 }

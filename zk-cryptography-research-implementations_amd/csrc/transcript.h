@@ -18,9 +18,17 @@ class Keccak256 {
   public:
     Keccak256() { memset(a_, 0, sizeof a_); fill_ = 0; }
     void update(const uint8_t *data, size_t n) {
-        // whole blocks straight from the caller's buffer: 17 little-endian lanes per block (the table absorb of
-        // Prover::prove, prover.rs:38-39, is 32 * 2^n bytes of sequential sponge input)
-        while (fill_ == 0 && n >= kRate) {
+        // (1) finish an open block byte by byte, (2) whole blocks straight from the caller's buffer as 17 little-endian lanes
+        // (the table absorb of Prover::prove, prover.rs:38-39, is 32 * 2^n bytes of sequential sponge input and arrives in
+        // chunks that are not multiples of the rate), (3) keep the tail
+        if (fill_ != 0) {
+            size_t room = kRate - fill_, take = n < room ? n : room;
+            xor_in(data, take);
+            data += take;
+            n -= take;
+            if (fill_ == kRate) { permute(); fill_ = 0; }
+        }
+        while (n >= kRate) {                                 // here fill_ == 0
             for (int i = 0; i < 17; i++) {
                 uint64_t w;
                 memcpy(&w, data + 8 * i, 8);
@@ -30,14 +38,7 @@ class Keccak256 {
             data += kRate;
             n -= kRate;
         }
-        while (n) {
-            size_t room = kRate - fill_;
-            size_t take = n < room ? n : room;
-            xor_in(data, take);
-            data += take;
-            n -= take;
-            if (fill_ == kRate) { permute(); fill_ = 0; }
-        }
+        if (n) xor_in(data, n);                              // < rate bytes into an empty block
     }
     // digest of everything absorbed so far; *this is left untouched
     void finalize_copy(uint8_t out[32]) const {

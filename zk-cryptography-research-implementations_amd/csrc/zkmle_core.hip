@@ -18,6 +18,8 @@ struct DeviceScratch {
     size_t dev_bytes = 0;
     void *host = nullptr;
     size_t host_bytes = 0;
+    void *pair[2] = {nullptr, nullptr};      // pinned double buffer of the transcript absorb
+    size_t pair_bytes = 0;
 };
 static std::mutex g_mu;
 static std::vector<DeviceScratch> g_scratch;
@@ -68,6 +70,23 @@ int host_staging(size_t bytes, void **out) {
         s->host_bytes = want;
     }
     *out = s->host;
+    return ZK_OK;
+}
+
+int pinned_pair(size_t bytes, void *out[2]) {
+    DeviceScratch *s;
+    ZK_TRY(current_scratch(&s));
+    if (s->pair_bytes < bytes) {
+        for (int k = 0; k < 2; k++) {
+            if (s->pair[k]) ZK_HIP(hipHostFree(s->pair[k]));
+            s->pair[k] = nullptr;
+        }
+        s->pair_bytes = 0;
+        for (int k = 0; k < 2; k++) ZK_HIP(hipHostMalloc(&s->pair[k], bytes, hipHostMallocDefault));
+        s->pair_bytes = bytes;
+    }
+    out[0] = s->pair[0];
+    out[1] = s->pair[1];
     return ZK_OK;
 }
 

@@ -177,11 +177,7 @@ template <class F> int gkr_prove(const zk_gate *gates, const size_t *gate_counts
     size_t w0len = w0.size() / L64;
     TablePtr w0t;
     ZK_TRY(upload_table(F::ID, w0.data(), w0len, w0t));                               // new(): pow2 assert
-    {
-        std::vector<uint8_t> bytes(w0len * 8 * L64);
-        ZK_TRY(zk_mle_to_bytes(w0t.get(), bytes.data()));
-        tr.t.append(bytes.data(), bytes.size());                                     // :49
-    }
+    ZK_TRY(transcript_absorb_table(tr.t, w0t.get()));                                // :49
     uint64_t ra[6], claim[6], alpha[6] = {0}, beta[6] = {0};
     store_el<F>(ra, tr.t.random_challenge_as_field_element<F>());                    // :50
     ZK_TRY(zk_mle_evaluate(w0t.get(), ra, 1, claim));                                // :51
@@ -235,11 +231,7 @@ template <class F> int gkr_verify(const zk_gate *gates, const size_t *gate_count
     if (output_len == 1) w0.resize(2 * L64, 0);
     TablePtr w0t;
     ZK_TRY(upload_table(F::ID, w0.data(), w0.size() / L64, w0t));
-    {
-        std::vector<uint8_t> bytes(w0.size() * 8);
-        ZK_TRY(zk_mle_to_bytes(w0t.get(), bytes.data()));
-        tr.t.append(bytes.data(), bytes.size());                                     // :161
-    }
+    ZK_TRY(transcript_absorb_table(tr.t, w0t.get()));                                // :161
     uint64_t ra[6], claim[6], alpha[6] = {0}, beta[6] = {0};
     store_el<F>(ra, tr.t.random_challenge_as_field_element<F>());                    // :162
     ZK_TRY(zk_mle_evaluate(w0t.get(), ra, 1, claim));                                // :164

@@ -220,11 +220,8 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
     size_t nout = (size_t)1 << out_bits[0];
     ZK_TRY(zk_table_download(W[0].get(), circuit_output));
     zk_transcript tr;
-    {   // transcript.append(w0 bytes) gkr_protocol.rs:49 (an output layer of one wire is one gate plus a zero pad, :43-47)
-        std::vector<uint8_t> bytes(nout * esz);
-        ZK_TRY(zk_mle_to_bytes(W[0].get(), bytes.data()));
-        tr.t.append(bytes.data(), bytes.size());
-    }
+    // transcript.append(w0 bytes) gkr_protocol.rs:49 (an output layer of one wire is one gate plus a zero pad, :43-47)
+    ZK_TRY(transcript_absorb_table(tr.t, W[0].get()));
     std::vector<uint64_t> ra((size_t)out_bits[0] * L64);
     for (uint32_t i = 0; i < out_bits[0]; i++) store_el<F>(ra.data() + i * L64, tr.t.random_challenge_as_field_element<F>());   // :50
     memcpy(output_challenges, ra.data(), ra.size() * 8);
