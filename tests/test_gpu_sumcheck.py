@@ -244,3 +244,40 @@ def test_sumcheck_provers_other_fields_beyond_the_tail(zk, field, logn):
     proof = zk.Prover.init(field, zk.MultilinearPolynomial(field, table)).prove()
     cs, rp, _ = O.sumcheck_basic_prove(field, table)
     assert np.array_equal(proof.initial_claimed_sum, cs) and np.array_equal(proof.round_univariate_polynomials, rp)
+
+
+@pytest.mark.gpu
+def test_two_host_threads_prove_concurrently(zk):
+    """Distinct handles may be driven from different threads (include/zkmle.h): reduction partials, staging buffers and the
+    per-call statistics are per thread, the caching pool is locked.  Two threads prove different statements at the same
+    time (ctypes drops the GIL inside the library); every proof must still equal the oracle's."""
+    import threading
+    field = 0
+    jobs = []
+    for k in range(2):
+        n = 1 << (12 + k)
+        tabs = np.stack([np.stack([rand_table(zk, field, n, 1300 + 10 * k + 2 * p + f) for f in range(2)]) for p in range(2)])
+        claimed = O.vec_sum(field, O.sumpoly_reduce(field, tabs))
+        co, ch = O.sumcheck_gkr_prove(field, tabs, claimed, O.Transcript())
+        cs, rp, _ = O.sumcheck_basic_prove(field, tabs[0, 0])
+        jobs.append((tabs, claimed, co, ch, cs, rp))
+    errors = []
+
+    def work(job):
+        tabs, claimed, co, ch, cs, rp = job
+        try:
+            for _ in range(5):
+                sp = mk_sum(zk, field, tabs)
+                res = zk.sumcheck.prove(sp, claimed, zk.Transcript())
+                assert np.array_equal(res.round_univariate_polynomials, co) and np.array_equal(res.random_challenges, ch)
+                proof = zk.Prover.init(field, zk.MultilinearPolynomial(field, tabs[0, 0])).prove()
+                assert np.array_equal(proof.initial_claimed_sum, cs) and np.array_equal(proof.round_univariate_polynomials, rp)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -21,8 +21,21 @@ struct DeviceScratch {
     void *pair[2] = {nullptr, nullptr};      // pinned double buffer of the transcript absorb
     size_t pair_bytes = 0;
 };
-static std::mutex g_mu;
-static std::vector<DeviceScratch> g_scratch;
+static std::mutex g_mu;                                  // guards the caching pool
+// Reduction partials and staging buffers are per THREAD and per device: two threads driving distinct handles never share
+// them (a handle itself is used by one thread at a time, include/zkmle.h).  Freed when the thread ends.
+struct ScratchSet {
+    std::vector<DeviceScratch> v;
+    ~ScratchSet() {
+        for (DeviceScratch &s : v) {
+            if (s.dev) (void)hipFree(s.dev);
+            if (s.host) (void)hipHostFree(s.host);
+            for (void *p : s.pair)
+                if (p) (void)hipHostFree(p);
+        }
+    }
+};
+static thread_local ScratchSet g_scratch;
 
 int require_device() {
     int n = 0;
@@ -37,9 +50,8 @@ int require_device() {
 static int current_scratch(DeviceScratch **out) {
     int dev = 0;
     ZK_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_mu);
-    if ((int)g_scratch.size() <= dev) g_scratch.resize(dev + 1);
-    *out = &g_scratch[dev];
+    if ((int)g_scratch.v.size() <= dev) g_scratch.v.resize(dev + 1);
+    *out = &g_scratch.v[dev];
     return ZK_OK;
 }
 
