@@ -40,6 +40,21 @@ pub mod ffi {
         pub fn zk_kzg_commit(poly: *const zk_table, g1: *const zk_g1_bases, out12: *mut u64) -> c_int;
         pub fn zk_kzg_open(poly: *const zk_table, g1: *const zk_g1_bases, key: *const c_void, opening: *const u64,
                            nopen: usize, n_g2: usize, evaluation: *mut u64, proofs: *mut u64) -> c_int;
+        pub fn zk_kzg_setup_g1(taus: *const u64, ntaus: usize, out: *mut *mut zk_g1_bases) -> c_int;
+        pub fn zk_kzg_setup_g2(taus: *const u64, ntaus: usize, out24: *mut u64) -> c_int;
+        pub fn zk_kzg_verify(commitment12: *const u64, opening: *const u64, nopen: usize, evaluation: *const u64, proofs: *const u64,
+                             nproofs: usize, g2_powers: *const u64, ng2: usize, ok: *mut c_int) -> c_int;
+        // device-resident rounds for one-process-per-GPU provers
+        pub fn zk_rounds_new(field: c_int, mode: c_int, nprod: usize, nfac: usize, nrounds: usize, t: *mut zk_transcript,
+                             out: *mut *mut c_void) -> c_int;
+        pub fn zk_rounds_limbs_len(r: *const c_void) -> usize;
+        pub fn zk_rounds_evals(r: *mut c_void, tables: *const *const zk_table, limbs_dev: *mut u64) -> c_int;
+        pub fn zk_rounds_fold_evals(r: *mut c_void, inp: *const *const zk_table, out: *const *mut zk_table, limbs_dev: *mut u64) -> c_int;
+        pub fn zk_rounds_absorb(r: *mut c_void, limbs_dev: *const u64) -> c_int;
+        pub fn zk_rounds_tail(r: *mut c_void, tables: *const *const zk_table) -> c_int;
+        pub fn zk_rounds_collect(r: *mut c_void, t: *mut zk_transcript, claimed: *mut u64, messages: *mut u64, challenges: *mut u64,
+                                 final_values: *mut u64) -> c_int;
+        pub fn zk_rounds_free(r: *mut c_void) -> c_int;
     }
 }
 
@@ -131,5 +146,61 @@ impl<F: ZkField> Prover<F> {
         }
     }
 }
-// sumcheck_gkr_protocol::prove, gkr_protocol::prove, MultilinearKZG::{commit_to_polynomial, open_and_prove}
-// bind zk_sumcheck_gkr_prove / zk_gkr_prove / zk_kzg_commit / zk_kzg_open the same way.
+
+/// multilinear_kzg::{TrustedSetup, MultilinearKZG} for P = Bls12_381, F = Fr (multilinear_kzg.rs:22-158).
+/// G1 points cross the ABI as affine x || y (12 u64 Montgomery limbs, (0, 0) = infinity), G2 as x.c0 || x.c1 || y.c0 || y.c1.
+pub mod kzg {
+    use super::*;
+    use ark_bls12_381::{Fq, Fr, G1Affine, G1Projective};
+    use ark_ec::{AffineRepr, CurveGroup};
+
+    fn g1_to_limbs(p: &G1Projective) -> [u64; 12] {
+        let a = p.into_affine();
+        let mut out = [0u64; 12];
+        if let Some((x, y)) = a.xy() {
+            out[..6].copy_from_slice(&x.0 .0);                   // Fp<_, 6>.0 = BigInt([u64; 6]), Montgomery form
+            out[6..].copy_from_slice(&y.0 .0);
+        }
+        out
+    }
+    fn g1_from_limbs(l: &[u64]) -> G1Projective {
+        if l.iter().all(|&w| w == 0) { return G1Projective::default(); }
+        let fq = |w: &[u64]| Fq::new_unchecked(ark_ff::BigInt::new(w.try_into().unwrap()));
+        G1Affine::new_unchecked(fq(&l[..6]), fq(&l[6..])).into()
+    }
+
+    pub struct TrustedSetup { pub g1: *mut ffi::zk_g1_bases, pub g2_powers: Vec<u64>, pub nvars: usize }
+    impl TrustedSetup {
+        pub fn initialize_setup(taus: &[Fr]) -> Self {                           // trusted_setup.rs:11-22
+            let mut g1 = std::ptr::null_mut();
+            check(unsafe { ffi::zk_kzg_setup_g1(as_limbs(taus), taus.len(), &mut g1) });
+            let mut g2 = vec![0u64; 24 * taus.len()];
+            check(unsafe { ffi::zk_kzg_setup_g2(as_limbs(taus), taus.len(), g2.as_mut_ptr()) });
+            Self { g1, g2_powers: g2, nvars: taus.len() }
+        }
+    }
+    pub struct MultilinearKZGProof { pub evaluation: Fr, pub proofs: Vec<G1Projective> }   // multilinear_kzg.rs:17-20
+
+    pub fn commit_to_polynomial(poly: &MultilinearPolynomial<Fr>, setup: &TrustedSetup) -> G1Projective {   // :25-45
+        let t = DeviceTable::<Fr>::upload(&poly.evaluated_values);
+        let mut out = [0u64; 12];
+        check(unsafe { ffi::zk_kzg_commit(t.h, setup.g1, out.as_mut_ptr()) });
+        g1_from_limbs(&out)
+    }
+    pub fn open_and_prove(poly: &MultilinearPolynomial<Fr>, setup: &TrustedSetup, opening: &[Fr]) -> MultilinearKZGProof {   // :50-126
+        let t = DeviceTable::<Fr>::upload(&poly.evaluated_values);
+        let (mut ev, mut proofs) = (Fr::from(0u64), vec![0u64; 12 * opening.len().max(1)]);
+        check(unsafe { ffi::zk_kzg_open(t.h, setup.g1, std::ptr::null(), as_limbs(opening), opening.len(), setup.nvars,
+                                        &mut ev as *mut Fr as *mut u64, proofs.as_mut_ptr()) });
+        MultilinearKZGProof { evaluation: ev, proofs: proofs.chunks(12).take(opening.len()).map(g1_from_limbs).collect() }
+    }
+    pub fn verify(setup: &TrustedSetup, commitment: &G1Projective, opening: &[Fr], proof: &MultilinearKZGProof) -> bool {    // :131-158
+        let c = g1_to_limbs(commitment);
+        let prs: Vec<u64> = proof.proofs.iter().flat_map(|p| g1_to_limbs(p)).collect();
+        let mut ok: c_int = 0;
+        check(unsafe { ffi::zk_kzg_verify(c.as_ptr(), as_limbs(opening), opening.len(), &proof.evaluation as *const Fr as *const u64,
+                                          prs.as_ptr(), proof.proofs.len(), setup.g2_powers.as_ptr(), setup.nvars, &mut ok) });
+        ok == 1
+    }
+}
+// sumcheck_gkr_protocol::prove and gkr_protocol::prove bind zk_sumcheck_gkr_prove / zk_gkr_prove the same way.
