@@ -59,6 +59,17 @@ __global__ void msm_digits_kernel(const void *__restrict__ scalars, size_t n, un
 // pass 1: per (chunk, window) histogram in LDS -> hist[(w * nchunks + chunk) * nb + b]
 // `by_chunk`: the output slot of block (w, chunk) is (chunk, w) instead of (w, chunk): every chunk is a bucket set of its
 // own that ALL windows feed (batched MSMs on window-shifted bases, zkmle_kzg.hip msm_core)
+// `by_chunk` = g > 0 additionally makes the chunks the halving ranges of a KZG opening's levels laid end to end:
+// chunk j = [2^g - 2^(g-j), +2^(g-1-j)), g = by_chunk (chunk_len is ignored).
+__device__ __forceinline__ void msm_chunk_range(unsigned chunk, size_t chunk_len, size_t n, unsigned by_chunk, size_t &lo, size_t &hi) {
+    if (by_chunk) {
+        lo = ((size_t)1 << by_chunk) - ((size_t)1 << (by_chunk - chunk));
+        hi = lo + ((size_t)1 << (by_chunk - 1 - chunk));
+    } else {
+        lo = (size_t)chunk * chunk_len;
+        hi = lo + chunk_len < n ? lo + chunk_len : n;
+    }
+}
 __global__ void msm_hist_kernel(const uint16_t *__restrict__ digits, size_t n, unsigned c, unsigned nchunks,
                                 size_t chunk_len, uint32_t *__restrict__ hist, unsigned by_chunk) {
     extern __shared__ uint32_t lds[];
@@ -66,7 +77,8 @@ __global__ void msm_hist_kernel(const uint16_t *__restrict__ digits, size_t n, u
     unsigned chunk = blockIdx.x % nchunks, w = blockIdx.x / nchunks;
     for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = 0;
     __syncthreads();
-    size_t lo = (size_t)chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    size_t lo, hi;
+    msm_chunk_range(chunk, chunk_len, n, by_chunk, lo, hi);
     const uint16_t *d = digits + (size_t)w * n;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         unsigned enc = d[i];
@@ -209,7 +221,8 @@ __global__ void msm_scatter_kernel(const uint16_t *__restrict__ digits, size_t n
     const uint32_t *off = hist + (by_chunk ? (size_t)chunk * nwin + w : (size_t)w * nchunks + chunk) * nb;
     for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = off[b];
     __syncthreads();
-    size_t lo = (size_t)chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    size_t lo, hi;
+    msm_chunk_range(chunk, chunk_len, n, by_chunk, lo, hi);
     const uint16_t *d = digits + (size_t)w * n;
     const uint64_t *st = starts + (size_t)(by_chunk ? chunk : w) * nb;
     const size_t base = by_chunk ? (size_t)w * n : 0;

@@ -1,6 +1,7 @@
 // zkmle_kzg.hip -- C ABI: G1 bases in HBM, Pippenger MSM, and the multilinear-KZG prover side
 // (trusted-setup G1 powers, commit, open).  Mirrors multilinear_kzg/src/{multilinear_kzg,trusted_setup}.rs;
 // pairing-based `verify` (G2 / GT) is out of scope.
+#include <stdlib.h>
 #include <string.h>
 
 #include <memory>
@@ -23,14 +24,25 @@ struct zk_kzg_opening_key {
     // level[t] (t = 1..nvars): 2^(nvars - t) pre-summed affine bases B^(t)_k = sum_{h < 2^t} B_{h 2^(nvars-t) + k}
     std::vector<zk_g1_bases *> level;
     size_t nvars;
-    // the levels of <= 2^kOpenBatchBits bases once more, pre-converted and padded to one stride: small_u[j][k], j = t - small_t0,
+    // the levels of <= 2^open_batch_bits() bases once more, pre-converted, one copy per window: level j = t - small_t0,
     // so that their MSMs run as ONE batched pass (msm_core)
-    void *small_u = nullptr;      // [window][j][k] = 2^(small_c * window) B^(small_t0 + j)_k, pre-converted (msm_core, shifted)
-    unsigned small_bits = 0;      // stride = 2^small_bits points
+    void *small_u = nullptr;      // [window][off_j + k] = 2^(small_c * window) B^(small_t0 + j)_k, pre-converted (msm_core, shifted);
+                                  // the levels lie end to end, off_j = 2^(small_bits + 1) - 2^(small_bits + 1 - j)
+    unsigned small_bits = 0;      // the first batched level has 2^small_bits points
     size_t small_t0 = 0;          // first batched level
     int small_c = 0;              // window size of the batched pass
 };
-constexpr unsigned kOpenBatchBits = 13;
+// levels of at most 2^open_batch_bits() bases are batched.  Default 19: 2^20 points x 16 windows x 128 B = 2 GiB per opening key
+// at most, +30 ms to build it; measured r1 (open_and_prove, ms, bits = 13 / 16 / 19): 2^16 7.0 / 3.3 / 3.4, 2^20 21.6 / 15.9 / 10.5,
+// 2^24 87 / 81 / 77 (profiles/r1/bench_kzg_e2e.jsonl).  ZK_KZG_OPEN_BATCH_BITS overrides, for measurements.
+static unsigned open_batch_bits() {
+    static const unsigned v = [] {
+        const char *e = getenv("ZK_KZG_OPEN_BATCH_BITS");
+        int k = e ? atoi(e) : 19;
+        return (unsigned)(k < 1 ? 1 : (k > 22 ? 22 : k));
+    }();
+    return v;
+}
 
 namespace {
 
@@ -74,19 +86,20 @@ int pick_window(size_t n) {
 
 int bases_u(const zk_g1_bases *b, const void **out);
 
-// `batch` independent MSMs of n_sub terms each in ONE pass of the pipeline: sum_i [s_{j,i}] B_{j,i} for j < batch, scalars
-// stored [j][i].  Small MSMs are pure latency (a 2^12-term MSM takes ~1.6 ms of dependent launches and single-lane addition
+// `batch` independent MSMs in ONE pass of the pipeline.  Small MSMs are pure latency (a 2^12-term MSM takes ~1.6 ms of dependent launches and single-lane addition
 // chains whatever its size, plus a serial window combination), so the n MSMs of a KZG opening share one pass.
-// shifted = false (batch must be 1): the plain MSM, d_bases = the pre-converted points.
-// shifted = true: d_bases holds one copy of the points per window, [w][j][i] = 2^(c w) B_{j,i} (c must be given): every
-// window of MSM j feeds the SAME bucket set, so there are `batch` bucket sets, one reduction each and no window combination.
+// shifted = false (batch must be 1): the plain MSM of n_sub terms, d_bases = the pre-converted points.
+// shifted = true: the MSMs are the halving levels of a KZG opening laid end to end, MSM j = 2^(batch-1-j) terms starting at
+// 2^batch - 2^(batch-j) (n_sub = the first level's size = 2^(batch-1)), and d_bases holds one copy of the points per
+// window, [w][i] = 2^(c w) B_i (c must be given): every window of MSM j feeds the SAME bucket set, so there are `batch` bucket
+// sets, one reduction each and no window combination.
 // results: `batch` XYZZ points on the host.
 int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned batch, bool shifted, int c, G1Xyzz *result,
              zk_msm_stats *stats) {
-    const size_t n = n_sub * batch;                         // digit stream: [window][j][i]
+    if (batch == 0 || (!shifted && batch != 1) || (shifted && n_sub != ((size_t)1 << (batch - 1)))) return ZK_E_ARG;
+    const size_t n = shifted ? ((size_t)1 << batch) - 1 : n_sub;   // digit stream: [window][i]
     if (c == 0) c = pick_window(n_sub);
     if (c < 2 || c > 16) return ZK_E_ARG;
-    if (batch == 0 || (!shifted && batch != 1)) return ZK_E_ARG;
     const unsigned nwin1 = (256 + c - 1) / c, nb = 1u << (c - 1);
     if (n * (shifted ? nwin1 : 1) >= ((size_t)1 << 31)) return ZK_E_ARG;   // index + sign are packed in 32 bits
     const unsigned nwin = shifted ? batch : nwin1;          // bucket sets
@@ -96,8 +109,8 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     size_t chunk_len = (n + 15) / 16;
     if (chunk_len < 4096) chunk_len = 4096;
     unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
-    if (shifted) { chunk_len = n_sub; nchunks = batch; }    // chunk j = MSM j = bucket set j
-    const unsigned by_chunk = shifted ? 1u : 0u;
+    if (shifted) { chunk_len = 0; nchunks = batch; }        // chunk j = MSM j = bucket set j (msm_chunk_range)
+    const unsigned by_chunk = shifted ? batch : 0u;
     // one lane per bucket SEGMENT: cap the serial chain so that ~2^20 lanes exist whatever the window
     // size (measured r1: 2^20 terms, c = 14: 149k lanes -> 0.7e9 add/s; 521k lanes at c = 16 -> 2.1e9 add/s)
     size_t seg_target = ((size_t)n * nwin1) >> 20;
@@ -449,20 +462,20 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
         cur = key->level[t];
     }
     if (rc == ZK_OK && key->nvars >= 2) {                   // with one variable there is a single 1-term MSM: nothing to batch
-        key->small_bits = (unsigned)(key->nvars - 1 < kOpenBatchBits ? key->nvars - 1 : kOpenBatchBits);
+        key->small_bits = (unsigned)(key->nvars - 1 < open_batch_bits() ? key->nvars - 1 : open_batch_bits());
         key->small_t0 = key->nvars - key->small_bits;
-        const size_t stride = (size_t)1 << key->small_bits, nlev = key->small_bits + 1, total = nlev * stride;
-        key->small_c = pick_window(stride);
+        const size_t nlev = key->small_bits + 1, total = ((size_t)1 << nlev) - 1;
+        key->small_c = pick_window((size_t)1 << key->small_bits);
         const unsigned c = (unsigned)key->small_c, nwin = (256 + c - 1) / c;
-        DevBuf aff, xyzz;                                   // the levels side by side (padding = infinity), then shifted window by window
+        DevBuf aff, xyzz;                                   // the levels end to end, then shifted window by window
         rc = aff.alloc(total * sizeof(G1Affine));
         if (rc == ZK_OK) rc = xyzz.alloc(total * sizeof(G1Xyzz));
         hipError_t e = hipSuccess;
         if (rc == ZK_OK) e = hipMalloc(&key->small_u, (size_t)nwin * total * kBaseUBytes);
-        if (rc == ZK_OK && e == hipSuccess) e = hipMemsetAsync(aff.p, 0, total * sizeof(G1Affine), nullptr);
         for (size_t j = 0; j < nlev && rc == ZK_OK && e == hipSuccess; j++) {
             const zk_g1_bases *lv = key->level[key->small_t0 + j];
-            e = hipMemcpyAsync((char *)aff.p + j * stride * sizeof(G1Affine), lv->dptr, lv->n * sizeof(G1Affine), hipMemcpyDeviceToDevice, nullptr);
+            const size_t off = ((size_t)1 << nlev) - ((size_t)1 << (nlev - j));
+            e = hipMemcpyAsync((char *)aff.p + off * sizeof(G1Affine), lv->dptr, lv->n * sizeof(G1Affine), hipMemcpyDeviceToDevice, nullptr);
         }
         if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
         for (unsigned w = 0; w < nwin && rc == ZK_OK; w++) {
@@ -508,17 +521,15 @@ int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg
     if (rc == ZK_OK && poly->len >= 2) rc = zk_table_alloc(ZK_FR381, poly->len / 2, &q);
     // quotients of the batched (small) levels are collected, zero-padded, in one scalar buffer [j][2^small_bits]
     const bool batched = key->small_u != nullptr && rc == ZK_OK;
-    const size_t stride = (size_t)1 << key->small_bits, nlev = key->small_bits + 1;
+    const size_t nlev = key->small_bits + 1, small_total = ((size_t)1 << nlev) - 1;
     DevBuf smallq;
-    if (batched) {
-        rc = smallq.alloc(nlev * stride * 32);
-        if (rc == ZK_OK && hipMemsetAsync(smallq.p, 0, nlev * stride * 32, nullptr) != hipSuccess) rc = ZK_E_HIP;
-    }
+    if (batched) rc = smallq.alloc(small_total * 32);
     for (size_t i = 0; i < nopen && rc == ZK_OK; i++) {                                          // :86
         size_t half = sub->len / 2;
         const size_t t = i + 1;
         const bool small = batched && t >= key->small_t0;
-        void *qdst = small ? (void *)((char *)smallq.p + (t - key->small_t0) * stride * 32) : q->dptr;
+        // batched level j = t - small_t0 sits at offset 2^nlev - 2^(nlev - j) of the end-to-end scalar buffer
+        void *qdst = small ? (void *)((char *)smallq.p + (((size_t)1 << nlev) - ((size_t)1 << (nlev - (t - key->small_t0)))) * 32) : q->dptr;
         // quotient = hi half - lo half (compute_quotient_polynomial :165-179)
         elementwise_kernel<Fr381, OP_HI_MINUS_LO><<<grid_for(half), kBlock>>>(sub->dptr, nullptr, qdst, half, fe_zero<Fr381>());
         hipError_t e = hipGetLastError();
@@ -537,7 +548,7 @@ int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg
     }
     if (batched && rc == ZK_OK) {                           // the small levels' proofs: one batched pass
         std::vector<G1Xyzz> pis(nlev);
-        rc = msm_core(smallq.p, key->small_u, stride, (unsigned)nlev, true, key->small_c, pis.data(), nullptr);
+        rc = msm_core(smallq.p, key->small_u, (size_t)1 << key->small_bits, (unsigned)nlev, true, key->small_c, pis.data(), nullptr);
         for (size_t j = 0; j < nlev && rc == ZK_OK; j++) affine_to_u64(g1_to_affine(pis[j]), proofs + 12 * (key->small_t0 + j - 1));
     }
     zk_table_free(sub);
