@@ -7,6 +7,8 @@
 // :49-57 / :108-163 (element-wise and tensor ops), sumcheck_protocol/src/basic_sumcheck/prover.rs:74-89
 // (half sums).
 #pragma once
+#include <stdlib.h>
+
 #include "ufield.cuh"
 
 namespace zk {
@@ -16,7 +18,7 @@ constexpr int kBlock = 256;          // 4 waves of 64
 // 2^23-output fold 5.28 TB/s at 32768 blocks vs 4.67 TB/s capped at 2048); reductions keep a
 // bounded grid because they emit one partial per block.
 constexpr int kMaxBlocks = 1 << 16;
-constexpr int kMaxReduceBlocks = 4096;   // measured r1 (2^24 fused round): 2048 -> 188 us, 4096 -> 158 us, 16384 -> 170 us
+constexpr int kMaxReduceBlocks = 16384;  // capacity of the partial buffers; the launch cap is reduce_block_cap()
 
 // ---- synthetic data: SplitMix64 keyed by (seed, element index, word) -----------------
 ZK_HD uint64_t splitmix64(uint64_t x) {
@@ -260,6 +262,17 @@ inline int grid_for(size_t work, int cap = kMaxBlocks) {
     if (b > (size_t)cap) b = cap;
     return (int)b;
 }
-inline int reduce_grid_for(size_t work) { return grid_for(work, kMaxReduceBlocks); }
+// grid cap of the reduction kernels (one partial per block).  Measured r1, 2^24 fused round (fold_half_sums_kernel): with
+// modular sums 2048 -> 188 us, 4096 -> 158, 16384 -> 170; with the lazy sums 2048 / 4096 / 8192 / 16384 -> 143 / 144 / 139 / 142
+// (noise), while the one-workgroup finish kernel grows with the partial count (23 -> 34 us): 4096.  ZK_REDUCE_BLOCKS overrides.
+inline int reduce_block_cap() {
+    static const int v = [] {
+        const char *e = getenv("ZK_REDUCE_BLOCKS");
+        int k = e ? atoi(e) : 4096;
+        return k < 64 ? 64 : (k > kMaxReduceBlocks ? kMaxReduceBlocks : k);
+    }();
+    return v;
+}
+inline int reduce_grid_for(size_t work) { return grid_for(work, reduce_block_cap()); }
 
 }  // namespace zk
