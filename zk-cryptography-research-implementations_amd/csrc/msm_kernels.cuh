@@ -365,6 +365,7 @@ int launch_msm_bucket_sum(const void *bases, const uint32_t *sorted, const uint6
 int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_starts, const uint32_t *out_starts, size_t nbuckets,
                                 unsigned group, uint32_t nout, void *out_partials, hipStream_t s);
 constexpr size_t kBaseUBytes = 128;   // one pre-converted affine point (g1u.cuh)
+int launch_msm_window_sums(const void *A, const void *R, unsigned nwin, unsigned c, void *out, hipStream_t s);
 int launch_g1_bases_to_u(const void *affine, size_t n, void *out_u, hipStream_t s);
 int launch_g1_shift(const void *in_affine, size_t n, unsigned c, void *out_xyzz, hipStream_t s);   // out = 2^c * in
 int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, hipStream_t s);

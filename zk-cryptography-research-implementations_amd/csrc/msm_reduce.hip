@@ -24,8 +24,8 @@ __global__ void __launch_bounds__(256) msm_partials_regroup_kernel(const void *_
     g1_store_xyzz(out_partials, t, acc);
 }
 
-// bucket (w, b) = sum of its segments' partials, written to slot b + 1 of window w in the
-// 2^c-slot reduction array A (slot index = digit magnitude)
+// bucket (w, b) = sum of its segments' partials, written to slot b of window w in the 2^(c-1)-slot reduction array A
+// (slot b holds digit magnitude b + 1)
 __global__ void __launch_bounds__(256) msm_bucket_combine_kernel(const void *__restrict__ partials, const uint32_t *__restrict__ seg_starts,
                                           unsigned nwin, unsigned c, void *__restrict__ A) {
     unsigned nb = 1u << (c - 1);
@@ -35,21 +35,40 @@ __global__ void __launch_bounds__(256) msm_bucket_combine_kernel(const void *__r
     uint32_t s0 = seg_starts[id], s1 = seg_starts[id + 1];
     G1Xyzz acc = g1_xyzz_inf();
     for (uint32_t s = s0; s < s1; s++) acc = g1_add(acc, g1_load_xyzz(partials, s));
-    g1_store_xyzz(A, ((size_t)w << c) + b + 1, acc);
+    g1_store_xyzz(A, ((size_t)w << (c - 1)) + b, acc);
 }
 
-// step 4: one halving level, in place.  half = current length / 2
+// step 4: one halving level of  sum_b b A[b]  over the 2^(c-1) slots of every window, in place (half = current length / 2):
+// A' = A_lo + A_hi, R' = A_hi + 2 (R_lo + R_hi), ending with R[0] = sum_b b A[b] and A[0] = sum_b A[b].  The slot weights are
+// b + 1, so the window sum is R[0] + A[0] (msm_window_sums_kernel): one level and half the array less than reducing 2^c slots
+// indexed by the digit magnitude itself (r1: 1.75 -> see DESIGN.md).
+// The two updates of a pair are independent (A' writes the low half of A, R' reads the high half of A), so they run in
+// different lanes: the first nwin * half lanes take A', the next nwin * half take R' -- the level's critical path is
+// add, double, add instead of those plus one more add (the late levels are pure latency).
 __global__ void __launch_bounds__(256) msm_reduce_level_kernel(void *__restrict__ A, void *__restrict__ R, unsigned nwin, unsigned c, size_t half) {
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (size_t)nwin * half) return;
+    const size_t work = (size_t)nwin * half;
+    if (id >= 2 * work) return;
+    const bool second = id >= work;
+    if (second) id -= work;
     size_t w = id / half, b = id % half;
-    size_t base = w << c;
-    G1Xyzz alo = g1_load_xyzz(A, base + b), ahi = g1_load_xyzz(A, base + b + half);
-    G1Xyzz rlo = g1_load_xyzz(R, base + b), rhi = g1_load_xyzz(R, base + b + half);
-    g1_store_xyzz(A, base + b, g1_add(alo, ahi));
-    g1_store_xyzz(R, base + b, g1_add(ahi, g1_dbl(g1_add(rlo, rhi))));
+    size_t base = w << (c - 1);
+    G1Xyzz ahi = g1_load_xyzz(A, base + b + half);
+    if (!second) {
+        g1_store_xyzz(A, base + b, g1_add(g1_load_xyzz(A, base + b), ahi));
+    } else {
+        G1Xyzz rlo = g1_load_xyzz(R, base + b), rhi = g1_load_xyzz(R, base + b + half);
+        g1_store_xyzz(R, base + b, g1_add(ahi, g1_dbl(g1_add(rlo, rhi))));
+    }
 }
 
+
+__global__ void msm_window_sums_kernel(const void *__restrict__ A, const void *__restrict__ R, unsigned nwin, unsigned c, void *__restrict__ out) {
+    unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    size_t base = (size_t)w << (c - 1);
+    g1_store_xyzz(out, w, g1_add(g1_load_xyzz(R, base), g1_load_xyzz(A, base)));
+}
 
 int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_starts, const uint32_t *out_starts, size_t nbuckets,
                                 unsigned group, uint32_t nout, void *out_partials, hipStream_t s) {
@@ -63,8 +82,13 @@ int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, 
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
+int launch_msm_window_sums(const void *A, const void *R, unsigned nwin, unsigned c, void *out, hipStream_t s) {
+    msm_window_sums_kernel<<<(nwin + 63) / 64, 64, 0, s>>>(A, R, nwin, c, out);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
 int launch_msm_reduce_level(void *A, void *R, unsigned nwin, unsigned c, size_t half, hipStream_t s) {
-    size_t work = (size_t)nwin * half;
+    size_t work = 2 * (size_t)nwin * half;
     msm_reduce_level_kernel<<<(unsigned)((work + 255) / 256), 256, 0, s>>>(A, R, nwin, c, half);
     ZK_HIP(hipGetLastError());
     return ZK_OK;

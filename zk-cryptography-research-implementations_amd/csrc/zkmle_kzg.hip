@@ -186,7 +186,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     ZK_TRY(ev.mark());
     // bucket sums
     ZK_TRY(partials.alloc(((size_t)nseg ? nseg : 1) * sizeof(G1Xyzz)));
-    size_t red_bytes = ((size_t)nwin << c) * sizeof(G1Xyzz);
+    size_t red_bytes = ((size_t)nwin << (c - 1)) * sizeof(G1Xyzz);
     ZK_TRY(A.alloc(red_bytes));
     ZK_TRY(R.alloc(red_bytes));
     ZK_HIP(hipMemsetAsync(A.p, 0, red_bytes, nullptr));     // all-zero XYZZ = infinity (ZZ = 0)
@@ -217,14 +217,16 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     }
     ZK_TRY(launch_msm_bucket_combine(cur_partials, cur_starts, nwin, (unsigned)c, A.p, nullptr));
     ZK_TRY(ev.mark());
-    // bucket reduction: c halving levels, in place
-    for (size_t half = (size_t)1 << (c - 1); half >= 1; half >>= 1) {
+    // bucket reduction: c - 1 halving levels over the 2^(c-1) slots of every window, in place; window sum = R[0] + A[0]
+    for (size_t half = (size_t)1 << (c - 2); half >= 1; half >>= 1) {
         ZK_TRY(launch_msm_reduce_level(A.p, R.p, nwin, (unsigned)c, half, nullptr));
         if (half == 1) break;
     }
     std::vector<G1Xyzz> sums(nwin);
-    for (unsigned w = 0; w < nwin; w++)
-        ZK_HIP(hipMemcpyAsync(&sums[w], (char *)R.p + ((size_t)w << c) * sizeof(G1Xyzz), sizeof(G1Xyzz), hipMemcpyDeviceToHost, nullptr));
+    DevBuf wsums;
+    ZK_TRY(wsums.alloc((size_t)nwin * sizeof(G1Xyzz)));
+    ZK_TRY(launch_msm_window_sums(A.p, R.p, nwin, (unsigned)c, wsums.p, nullptr));
+    ZK_HIP(hipMemcpyAsync(sums.data(), wsums.p, (size_t)nwin * sizeof(G1Xyzz), hipMemcpyDeviceToHost, nullptr));
     ZK_TRY(ev.mark());
     ZK_HIP(hipDeviceSynchronize());
     if (shifted) {                                          // the shifts live in the bases: bucket set j IS MSM j
