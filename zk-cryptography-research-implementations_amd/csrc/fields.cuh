@@ -196,6 +196,51 @@ template <class F> ZK_HD Fe<F> fe_mul_cios(const Fe<F> &a, const Fe<F> &b) {
     return r;
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host product: the same CIOS on N/2 64-bit limbs with 128-bit accumulators (x86-64 mulx / adcx), ~4x the 32-bit form.  The
+// host runs the control path on it: transcript challenges, interpolation, G1 / G2 group laws, the pairing.
+template <class F> inline Fe<F> fe_mul_host64(const Fe<F> &a, const Fe<F> &b) {
+    constexpr int M = F::N / 2;
+    typedef unsigned __int128 u128;
+    uint64_t x[M], y[M], p[M], t[M + 2];
+    for (int i = 0; i < M; i++) {
+        x[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+        y[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+        p[i] = (uint64_t)F::p(2 * i) | ((uint64_t)F::p(2 * i + 1) << 32);
+    }
+    uint64_t pinv = (uint64_t)(uint32_t)(0u - F::INV);       // p^-1 mod 2^32; one Newton step doubles the precision
+    pinv *= 2 - p[0] * pinv;
+    const uint64_t inv = 0 - pinv;                           // -p^-1 mod 2^64
+    for (int i = 0; i < M + 2; i++) t[i] = 0;
+    for (int i = 0; i < M; i++) {
+        u128 c = 0;
+        for (int j = 0; j < M; j++) {
+            c += (u128)x[j] * y[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[M];
+        t[M] = (uint64_t)c;
+        t[M + 1] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * inv;
+        c = (u128)m * p[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < M; j++) {
+            c += (u128)m * p[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[M];
+        t[M - 1] = (uint64_t)c;
+        t[M] = t[M + 1] + (uint64_t)(c >> 64);
+    }
+    Fe<F> r;
+    for (int i = 0; i < M; i++) { r.l[2 * i] = (uint32_t)t[i]; r.l[2 * i + 1] = (uint32_t)(t[i] >> 32); }
+    fe_cond_sub_p<F>(r, (uint32_t)t[M]);
+    return r;
+}
+#endif
+
 // fe_mul / fe_sqr / fe_inv / canonical conversions are defined in ufield.cuh (the device product is the
 // unsaturated 29-bit scan; fe_mul_cios above is the saturated reference form used on the host).
 

@@ -319,12 +319,12 @@ template <class F> ZK_HD Fe<F> u_to_std(const Ufe<F> &x) {          // x R_u -> 
 
 // ---- the library's field product --------------------------------------------------------------------------------
 // device: unsaturated scan (1.45x the saturated CIOS as hipcc compiles it, 1.9x without the conversions);
-// host:   saturated CIOS.  Both are fully reduced, hence bit-identical.
+// host:   saturated CIOS on 64-bit limbs (fields.cuh).  Both are fully reduced, hence bit-identical.
 template <class F> ZK_HD Fe<F> fe_mul(const Fe<F> &a, const Fe<F> &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return fe_mul_u<F>(a, b);
 #else
-    return fe_mul_cios<F>(a, b);
+    return fe_mul_host64<F>(a, b);
 #endif
 }
 
