@@ -365,6 +365,9 @@ int launch_msm_bucket_sum(const void *bases, const uint32_t *sorted, const uint6
 int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_starts, const uint32_t *out_starts, size_t nbuckets,
                                 unsigned group, uint32_t nout, void *out_partials, hipStream_t s);
 constexpr size_t kBaseUBytes = 128;   // one pre-converted affine point (g1u.cuh)
+int launch_msm_plain_level(void *A, void *B, unsigned nwin, unsigned cm1, unsigned k, size_t hh, size_t lh, hipStream_t s);
+int launch_msm_gather_cd(const void *A, const void *B, unsigned nwin, unsigned cm1, unsigned k, unsigned mbits, void *X, hipStream_t s);
+int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsigned mbits, void *out, hipStream_t s);
 int launch_msm_window_sums(const void *A, const void *R, unsigned nwin, unsigned c, void *out, hipStream_t s);
 int launch_g1_bases_to_u(const void *affine, size_t n, void *out_u, hipStream_t s);
 int launch_g1_shift(const void *in_affine, size_t n, unsigned c, void *out_xyzz, hipStream_t s);   // out = 2^c * in

@@ -63,6 +63,51 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(void *__restrict_
 }
 
 
+// ---- two-stage form of the weighted bucket sum -----------------------------------------------------------------------------------
+// sum_b (b + 1) A[b] over nb = H * L slots, b = h L + l:   = L * sum_h h D[h]  +  sum_l (l + 1) C[l],
+// with the plain sums C[l] = sum_h A[h][l] and D[h] = sum_l A[h][l].  The plain sums are halving trees of ONE addition per
+// level (A reduces over h in place, a copy of it reduces over l), and only the two short arrays C and D go through the
+// 3-operation weighted levels: log2(nb) levels of (add, double, add) become log2(H) plain + log2(L) weighted levels.
+__global__ void __launch_bounds__(256) msm_plain_level_kernel(void *__restrict__ A, void *__restrict__ B, unsigned nwin, unsigned cm1, unsigned k,
+                                                              size_t hh, size_t lh) {
+    // role 1: A[w][h][l] += A[w][h + hh][l], h < hh (all l);  role 2: B[w][h][l] += B[w][h][l + lh], l < lh (all h)
+    const size_t L = (size_t)1 << k, H = (size_t)1 << (cm1 - k);
+    const size_t work1 = (size_t)nwin * hh * L, work2 = (size_t)nwin * H * lh;
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < work1) {
+        size_t w = id / (hh * L), r = id % (hh * L);
+        size_t base = (w << cm1) + r;
+        g1_store_xyzz(A, base, g1_add(g1_load_xyzz(A, base), g1_load_xyzz(A, base + hh * L)));
+    } else if (id < work1 + work2) {
+        id -= work1;
+        size_t w = id / (H * lh), r = id % (H * lh);
+        size_t h = r / lh, l = r % lh;
+        size_t base = (w << cm1) + h * L + l;
+        g1_store_xyzz(B, base, g1_add(g1_load_xyzz(B, base), g1_load_xyzz(B, base + lh)));
+    }
+}
+// compact the two short arrays, zero-padded to M = 2^mbits entries: X[0][w][l] = C[l] = A[w][l],  X[1][w][h] = D[h] = B[w][h L]
+__global__ void msm_gather_cd_kernel(const void *__restrict__ A, const void *__restrict__ B, unsigned nwin, unsigned cm1, unsigned k, unsigned mbits,
+                                     void *__restrict__ X) {
+    const size_t L = (size_t)1 << k, H = (size_t)1 << (cm1 - k), M = (size_t)1 << mbits;
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2 * (size_t)nwin * M) return;
+    size_t p = id / ((size_t)nwin * M), r = id % ((size_t)nwin * M), w = r / M, i = r % M;
+    G1Xyzz v = g1_xyzz_inf();
+    if (p == 0) { if (i < L) v = g1_load_xyzz(A, (w << cm1) + i); }
+    else if (i < H) v = g1_load_xyzz(B, (w << cm1) + i * L);
+    g1_store_xyzz(X, id, v);
+}
+// out[3 w .. 3 w + 2] = sum_l l C[l], sum_l C[l], sum_h h D[h]  (R_l[0], A_l[0], R_h[0] of the weighted reductions)
+__global__ void msm_two_stage_out_kernel(const void *__restrict__ X, const void *__restrict__ Y, unsigned nwin, unsigned mbits, void *__restrict__ out) {
+    unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    const size_t M = (size_t)1 << mbits;
+    g1_store_xyzz(out, 3 * (size_t)w, g1_load_xyzz(Y, (size_t)w * M));
+    g1_store_xyzz(out, 3 * (size_t)w + 1, g1_load_xyzz(X, (size_t)w * M));
+    g1_store_xyzz(out, 3 * (size_t)w + 2, g1_load_xyzz(Y, ((size_t)nwin + w) * M));
+}
+
 __global__ void msm_window_sums_kernel(const void *__restrict__ A, const void *__restrict__ R, unsigned nwin, unsigned c, void *__restrict__ out) {
     unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwin) return;
@@ -84,6 +129,24 @@ int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, 
 }
 int launch_msm_window_sums(const void *A, const void *R, unsigned nwin, unsigned c, void *out, hipStream_t s) {
     msm_window_sums_kernel<<<(nwin + 63) / 64, 64, 0, s>>>(A, R, nwin, c, out);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int launch_msm_plain_level(void *A, void *B, unsigned nwin, unsigned cm1, unsigned k, size_t hh, size_t lh, hipStream_t s) {
+    size_t work = (size_t)nwin * ((hh << k) + (((size_t)1 << (cm1 - k)) * lh));
+    if (work == 0) return ZK_OK;
+    msm_plain_level_kernel<<<(unsigned)((work + 255) / 256), 256, 0, s>>>(A, B, nwin, cm1, k, hh, lh);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int launch_msm_gather_cd(const void *A, const void *B, unsigned nwin, unsigned cm1, unsigned k, unsigned mbits, void *X, hipStream_t s) {
+    size_t work = 2 * ((size_t)nwin << mbits);
+    msm_gather_cd_kernel<<<(unsigned)((work + 255) / 256), 256, 0, s>>>(A, B, nwin, cm1, k, mbits, X);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsigned mbits, void *out, hipStream_t s) {
+    msm_two_stage_out_kernel<<<(nwin + 63) / 64, 64, 0, s>>>(X, Y, nwin, mbits, out);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }

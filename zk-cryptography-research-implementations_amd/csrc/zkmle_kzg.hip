@@ -190,7 +190,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     ZK_TRY(A.alloc(red_bytes));
     ZK_TRY(R.alloc(red_bytes));
     ZK_HIP(hipMemsetAsync(A.p, 0, red_bytes, nullptr));     // all-zero XYZZ = infinity (ZZ = 0)
-    ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, nullptr));
+    if (c < 6) ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, nullptr));
     if (nseg) {
         ZK_TRY(launch_msm_bucket_sum(d_bases, (const uint32_t *)sorted.p, (const uint64_t *)starts.p, (const uint32_t *)seg_starts.p,
                                      nbuckets, seg_len, nseg, partials.p, nullptr));
@@ -217,18 +217,49 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     }
     ZK_TRY(launch_msm_bucket_combine(cur_partials, cur_starts, nwin, (unsigned)c, A.p, nullptr));
     ZK_TRY(ev.mark());
-    // bucket reduction: c - 1 halving levels over the 2^(c-1) slots of every window, in place; window sum = R[0] + A[0]
-    for (size_t half = (size_t)1 << (c - 2); half >= 1; half >>= 1) {
-        ZK_TRY(launch_msm_reduce_level(A.p, R.p, nwin, (unsigned)c, half, nullptr));
-        if (half == 1) break;
-    }
     std::vector<G1Xyzz> sums(nwin);
-    DevBuf wsums;
-    ZK_TRY(wsums.alloc((size_t)nwin * sizeof(G1Xyzz)));
-    ZK_TRY(launch_msm_window_sums(A.p, R.p, nwin, (unsigned)c, wsums.p, nullptr));
-    ZK_HIP(hipMemcpyAsync(sums.data(), wsums.p, (size_t)nwin * sizeof(G1Xyzz), hipMemcpyDeviceToHost, nullptr));
-    ZK_TRY(ev.mark());
-    ZK_HIP(hipDeviceSynchronize());
+    if (c >= 6) {
+        // two-stage weighted bucket sum (msm_reduce.hip): slot b = h L + l weighs b + 1 = L h + (l + 1)
+        const unsigned cm1 = (unsigned)c - 1, k = cm1 / 2, hb = cm1 - k, mbits = hb > k ? hb : k;
+        ZK_HIP(hipMemcpyAsync(R.p, A.p, red_bytes, hipMemcpyDeviceToDevice, nullptr));      // the copy that reduces over l
+        for (unsigned lvl = 0; lvl < mbits; lvl++) {
+            size_t hh = lvl < hb ? ((size_t)1 << (hb - 1 - lvl)) : 0, lh = lvl < k ? ((size_t)1 << (k - 1 - lvl)) : 0;
+            ZK_TRY(launch_msm_plain_level(A.p, R.p, nwin, cm1, k, hh, lh, nullptr));
+        }
+        DevBuf X, Y, out3;                                  // X: the arrays C (per window) then D, zero-padded; Y: their R arrays
+        const size_t small_bytes = 2 * ((size_t)nwin << mbits) * sizeof(G1Xyzz);
+        ZK_TRY(X.alloc(small_bytes));
+        ZK_TRY(Y.alloc(small_bytes));
+        ZK_TRY(out3.alloc(3 * (size_t)nwin * sizeof(G1Xyzz)));
+        ZK_HIP(hipMemsetAsync(Y.p, 0, small_bytes, nullptr));
+        ZK_TRY(launch_msm_gather_cd(A.p, R.p, nwin, cm1, k, mbits, X.p, nullptr));
+        for (size_t half = (size_t)1 << (mbits - 1); half >= 1; half >>= 1) {   // 2 nwin problems of 2^mbits entries, 0-based weights
+            ZK_TRY(launch_msm_reduce_level(X.p, Y.p, 2 * nwin, mbits + 1, half, nullptr));
+            if (half == 1) break;
+        }
+        ZK_TRY(launch_msm_two_stage_out(X.p, Y.p, nwin, mbits, out3.p, nullptr));
+        std::vector<G1Xyzz> o(3 * (size_t)nwin);
+        ZK_HIP(hipMemcpyAsync(o.data(), out3.p, o.size() * sizeof(G1Xyzz), hipMemcpyDeviceToHost, nullptr));
+        ZK_TRY(ev.mark());
+        ZK_HIP(hipDeviceSynchronize());
+        for (unsigned w = 0; w < nwin; w++) {               // S_w = 2^k sum_h h D[h] + (sum_l l C[l] + sum_l C[l])
+            G1Xyzz hi = o[3 * (size_t)w + 2];
+            for (unsigned i = 0; i < k; i++) hi = g1_dbl(hi);
+            sums[w] = g1_add(hi, g1_add(o[3 * (size_t)w], o[3 * (size_t)w + 1]));
+        }
+    } else {
+        // c - 1 halving levels over the 2^(c-1) slots of every window, in place; window sum = R[0] + A[0]
+        for (size_t half = (size_t)1 << (c - 2); half >= 1; half >>= 1) {
+            ZK_TRY(launch_msm_reduce_level(A.p, R.p, nwin, (unsigned)c, half, nullptr));
+            if (half == 1) break;
+        }
+        DevBuf wsums;
+        ZK_TRY(wsums.alloc((size_t)nwin * sizeof(G1Xyzz)));
+        ZK_TRY(launch_msm_window_sums(A.p, R.p, nwin, (unsigned)c, wsums.p, nullptr));
+        ZK_HIP(hipMemcpyAsync(sums.data(), wsums.p, (size_t)nwin * sizeof(G1Xyzz), hipMemcpyDeviceToHost, nullptr));
+        ZK_TRY(ev.mark());
+        ZK_HIP(hipDeviceSynchronize());
+    }
     if (shifted) {                                          // the shifts live in the bases: bucket set j IS MSM j
         for (unsigned j = 0; j < batch; j++) result[j] = sums[j];
     } else {                                                // window combination (host, W points): acc = 2^c * acc + S_w
