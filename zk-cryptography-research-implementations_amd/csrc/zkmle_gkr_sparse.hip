@@ -217,7 +217,6 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
     if (ninputs != ((size_t)1 << layers[nlayers - 1].in_bits)) return ZK_E_LEN_MISMATCH;
     std::vector<TablePtr> W;
     ZK_TRY((evaluate_layers<F>(layers, inputs, ninputs, W)));                        // Circuit::evaluate (arithmetic_circuit.rs:65-109)
-    size_t nout = (size_t)1 << out_bits[0];
     ZK_TRY(zk_table_download(W[0].get(), circuit_output));
     zk_transcript tr;
     // transcript.append(w0 bytes) gkr_protocol.rs:49 (an output layer of one wire is one gate plus a zero pad, :43-47)
