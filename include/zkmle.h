@@ -54,6 +54,13 @@ int zk_device_count(int *count);
 int zk_init(int device);              /* select the device for the calling thread's later calls */
 int zk_field_limbs(int field);        /* u64 limbs per element (4 or 6), negative on bad field */
 int zk_device_synchronize(void);
+/* Streams and threads: every launch, copy and wait of the library runs on the CALLING THREAD's current stream -- the
+ * default (NULL) stream unless zk_set_stream was called on that thread.  A handle is used by one thread at a time; threads
+ * that set different streams run their calls concurrently on the device (scratch buffers, staging buffers and the *_stats
+ * are per thread; cached scratch blocks are reused only on the stream they last served).  The `stream` argument of the
+ * zk_mle_* calls, when not NULL, overrides the thread's stream for that call. */
+int zk_set_stream(void *hip_stream);
+void *zk_get_stream(void);
 int zk_release_cached_memory(void);   /* frees the library's cached per-call scratch (MSM workspaces) on the current device */
 
 /* ---- device-resident tables ----------------------------------------------------------------

@@ -250,7 +250,7 @@ def test_sumcheck_provers_other_fields_beyond_the_tail(zk, field, logn):
 def test_two_host_threads_prove_concurrently(zk):
     """Distinct handles may be driven from different threads (include/zkmle.h): reduction partials, staging buffers and the
     per-call statistics are per thread, the caching pool is locked.  Two threads prove different statements at the same
-    time (ctypes drops the GIL inside the library); every proof must still equal the oracle's."""
+    time, each on its own stream (ctypes drops the GIL inside the library); every proof must still equal the oracle's."""
     import threading
     field = 0
     jobs = []
@@ -262,10 +262,18 @@ def test_two_host_threads_prove_concurrently(zk):
         cs, rp, _ = O.sumcheck_basic_prove(field, tabs[0, 0])
         jobs.append((tabs, claimed, co, ch, cs, rp))
     errors = []
+    import ctypes as C
+    import torch
+    lib = zk.lib()
+    lib.zk_set_stream.argtypes = [C.c_void_p]
+    lib.zk_get_stream.restype = C.c_void_p
+    streams = [torch.cuda.Stream() for _ in jobs]           # each thread drives its own HIP stream (zk_set_stream)
 
-    def work(job):
+    def work(job, stream):
         tabs, claimed, co, ch, cs, rp = job
         try:
+            lib.zk_set_stream(C.c_void_p(stream.cuda_stream))
+            assert (lib.zk_get_stream() or 0) == stream.cuda_stream
             for _ in range(5):
                 sp = mk_sum(zk, field, tabs)
                 res = zk.sumcheck.prove(sp, claimed, zk.Transcript())
@@ -275,7 +283,7 @@ def test_two_host_threads_prove_concurrently(zk):
         except Exception as e:      # noqa: BLE001
             errors.append(repr(e))
 
-    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    threads = [threading.Thread(target=work, args=(j, st)) for j, st in zip(jobs, streams)]
     for t in threads:
         t.start()
     for t in threads:

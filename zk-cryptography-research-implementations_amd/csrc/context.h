@@ -29,14 +29,21 @@ void set_last_error(const std::string &s);
 
 // Fails loudly (ZK_E_NO_DEVICE) when there is no GPU: there is no CPU fallback in this library.
 int require_device();
+// The calling thread's current stream (zk_set_stream; the null stream by default).  Every kernel launch, copy and
+// synchronisation of the library goes through it, so threads that set different streams run their calls concurrently on
+// the device.  Scratch buffers, the caching pool and the statistics are per thread as well.
+hipStream_t cur_stream();
+hipError_t memcpy_on_stream(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);   // async copy + stream sync
+hipError_t memset_on_stream(void *dst, int value, size_t bytes);
 // device scratch for reduction partials: at least `bytes` bytes, owned per device, reused
 int scratch(size_t bytes, void **out);
 // pinned host staging for small results (a few field elements)
 int host_staging(size_t bytes, void **out);
 
 // Caching device allocator for per-call scratch (the MSM allocates several GB per call; hipMalloc / hipFree of
-// such blocks costs milliseconds).  Freed blocks are kept per device and reused by later calls of similar size;
-// zk_release_cached_memory() returns them to the driver.
+// such blocks costs milliseconds).  Freed blocks are kept per THREAD and device and reused by that thread's later calls of
+// similar size (stream-ordered: a thread's work runs on its current stream, and changing the stream synchronises the
+// old one first); zk_release_cached_memory() returns the calling thread's blocks to the driver.
 int pool_alloc(size_t bytes, void **out);
 void pool_free(void *p);
 

@@ -61,7 +61,7 @@ template <class F> struct EqBuilder {
                 if ((uint32_t)i < nbits) memcpy(pt.tau[i].l, point + (size_t)i * (F::N / 2), 4 * F::N);
                 else pt.tau[i] = fe_zero<F>();
             }
-            eq_direct_kernel<F><<<1, 64>>>(pt, (int)nbits, out);
+            eq_direct_kernel<F><<<1, 64, 0, cur_stream()>>>(pt, (int)nbits, out);
             ZK_HIP(hipGetLastError());
             return ZK_OK;
         }
@@ -74,7 +74,7 @@ template <class F> struct EqBuilder {
         ZK_TRY(build(point, hbits, hi));
         ZK_TRY(build(point + (size_t)hbits * (F::N / 2), lbits, lo));
         const size_t n = (size_t)1 << nbits;
-        eq_outer_kernel<F><<<grid_for(n), kBlock>>>(hi, lo, lbits, n, out);
+        eq_outer_kernel<F><<<grid_for(n), kBlock, 0, cur_stream()>>>(hi, lo, lbits, n, out);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }

@@ -13,6 +13,14 @@ namespace zk {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &s) { g_last_error = s; }
 
+static thread_local hipStream_t g_stream = nullptr;
+hipStream_t cur_stream() { return g_stream; }
+hipError_t memcpy_on_stream(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, g_stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(g_stream);
+}
+hipError_t memset_on_stream(void *dst, int value, size_t bytes) { return hipMemsetAsync(dst, value, bytes, g_stream); }
+
 struct DeviceScratch {
     void *dev = nullptr;
     size_t dev_bytes = 0;
@@ -102,7 +110,7 @@ int pinned_pair(size_t bytes, void *out[2]) {
     return ZK_OK;
 }
 
-struct PoolBlock { void *p; size_t cap; int dev; bool busy; };
+struct PoolBlock { void *p; size_t cap; int dev; bool busy; hipStream_t stream; };   // stream = the one its last user ran on
 static std::vector<PoolBlock> g_pool;
 static size_t g_pool_bytes = 0;
 static const size_t kPoolLimit = (size_t)48 << 30;      // cached + in-use scratch per process
@@ -115,14 +123,14 @@ int pool_alloc(size_t bytes, void **out) {
         std::lock_guard<std::mutex> lk(g_mu);
         PoolBlock *best = nullptr;
         for (PoolBlock &b : g_pool)
-            if (!b.busy && b.dev == dev && b.cap >= bytes && b.cap <= 2 * bytes + (1u << 20) && (!best || b.cap < best->cap)) best = &b;
+            if (!b.busy && b.dev == dev && b.stream == cur_stream() && b.cap >= bytes && b.cap <= 2 * bytes + (1u << 20) && (!best || b.cap < best->cap)) best = &b;
         if (best) { best->busy = true; *out = best->p; return ZK_OK; }
     }
     if (g_pool_bytes + bytes > kPoolLimit) ZK_TRY(zk_release_cached_memory());
     void *p = nullptr;
     ZK_HIP(hipMalloc(&p, bytes));
     std::lock_guard<std::mutex> lk(g_mu);
-    g_pool.push_back(PoolBlock{p, bytes, dev, true});
+    g_pool.push_back(PoolBlock{p, bytes, dev, true, cur_stream()});
     g_pool_bytes += bytes;
     *out = p;
     return ZK_OK;
@@ -157,7 +165,7 @@ using namespace zk;
 template <int OP> static int elementwise(const zk_table *a, const zk_table *b, const uint64_t *scalar, zk_table *out,
                                          size_t outlen, void *stream) {
     ZK_TRY(require_device());
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = stream ? (hipStream_t)stream : cur_stream();
     uint64_t zero[6] = {0, 0, 0, 0, 0, 0};
     const uint64_t *sc = scalar ? scalar : zero;
     ZK_DISPATCH_FIELD(a->field, (elementwise_kernel<F, OP><<<grid_for(outlen), kBlock, 0, s>>>(
@@ -224,6 +232,13 @@ int zk_device_synchronize(void) {
     ZK_HIP(hipDeviceSynchronize());
     return ZK_OK;
 }
+// The calling thread's stream for everything the library launches from now on (NULL = the default stream).  Cached scratch
+// blocks are reused only on the stream they were last used on, so no synchronisation is needed here.
+int zk_set_stream(void *stream) {
+    g_stream = (hipStream_t)stream;
+    return ZK_OK;
+}
+void *zk_get_stream(void) { return (void *)g_stream; }
 
 // ---- tables ---------------------------------------------------------------------------------------
 int zk_table_alloc(int field, size_t len, zk_table **out) {
@@ -243,7 +258,7 @@ int zk_table_upload(int field, const uint64_t *host, size_t len, zk_table **out)
 int zk_table_upload_raw(int field, const uint64_t *host, size_t len, zk_table **out) {
     if (!host || !out) return ZK_E_ARG;
     ZK_TRY(zk_table_alloc(field, len, out));
-    hipError_t e = hipMemcpy((*out)->dptr, host, len * (size_t)field_limbs64(field) * 8, hipMemcpyHostToDevice);
+    hipError_t e = zk::memcpy_on_stream((*out)->dptr, host, len * (size_t)field_limbs64(field) * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         zk_table_free(*out);
         *out = nullptr;
@@ -253,7 +268,7 @@ int zk_table_upload_raw(int field, const uint64_t *host, size_t len, zk_table **
 }
 int zk_table_download(const zk_table *t, uint64_t *host) {
     if (!t || !host) return ZK_E_ARG;
-    ZK_HIP(hipMemcpy(host, t->dptr, t->len * (size_t)field_limbs64(t->field) * 8, hipMemcpyDeviceToHost));
+    ZK_HIP(zk::memcpy_on_stream(host, t->dptr, t->len * (size_t)field_limbs64(t->field) * 8, hipMemcpyDeviceToHost));
     return ZK_OK;
 }
 int zk_table_free(zk_table *t) {
@@ -274,13 +289,13 @@ int zk_table_wrap(int field, void *device_ptr, size_t len, zk_table **out) {
 int zk_table_clone(const zk_table *t, zk_table **out) {
     if (!t || !out) return ZK_E_ARG;
     ZK_TRY(zk_table_alloc(t->field, t->len, out));
-    ZK_HIP(hipMemcpy((*out)->dptr, t->dptr, t->len * (size_t)field_limbs64(t->field) * 8, hipMemcpyDeviceToDevice));
+    ZK_HIP(zk::memcpy_on_stream((*out)->dptr, t->dptr, t->len * (size_t)field_limbs64(t->field) * 8, hipMemcpyDeviceToDevice));
     return ZK_OK;
 }
 int zk_table_fill_random(zk_table *t, uint64_t seed) {
     if (!t) return ZK_E_ARG;
     ZK_TRY(require_device());
-    ZK_DISPATCH_FIELD(t->field, (fill_random_kernel<F><<<grid_for(t->len), kBlock>>>(t->dptr, t->len, seed, 0)));
+    ZK_DISPATCH_FIELD(t->field, (fill_random_kernel<F><<<grid_for(t->len), kBlock, 0, cur_stream()>>>(t->dptr, t->len, seed, 0)));
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -306,7 +321,7 @@ int zk_mle_fold_ptr(int field, const void *d_in, size_t len, size_t var, const u
     ZK_TRY(require_device());
     size_t half = len / 2;
     unsigned power = n - 1 - (unsigned)var;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = stream ? (hipStream_t)stream : cur_stream();
     if (var == 0 && (half + kBlock - 1) / kBlock <= (size_t)0x7fffffff) {
         unsigned grid = (unsigned)((half + kBlock - 1) / kBlock);
         ZK_DISPATCH_FIELD(field, (fold0_kernel<F><<<grid, kBlock, 0, s>>>(d_in, d_out, half, load_host<F>(value))));
@@ -336,11 +351,11 @@ static int sums_impl(const zk_table *t, int nseg, uint64_t *out) {
     ZK_TRY(host_staging(esz * nseg, &host));
     void *res = (char *)part + esz * (size_t)grid * nseg;
     ZK_DISPATCH_FIELD(t->field, {
-        segment_sums_kernel<F><<<grid, kBlock>>>(t->dptr, seglen, nseg, part);
-        finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, nseg, res);
+        segment_sums_kernel<F><<<grid, kBlock, 0, cur_stream()>>>(t->dptr, seglen, nseg, part);
+        finish_sums_kernel<F><<<1, kBlock, 0, cur_stream()>>>(part, (size_t)grid, nseg, res);
     });
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpy(host, res, esz * nseg, hipMemcpyDeviceToHost));
+    ZK_HIP(zk::memcpy_on_stream(host, res, esz * nseg, hipMemcpyDeviceToHost));
     memcpy(out, host, esz * nseg);
     return ZK_OK;
 }
@@ -364,7 +379,7 @@ int zk_mle_fold_half_sums(const zk_table *in, const uint64_t *value, zk_table *o
     ZK_TRY(scratch(esz * ((size_t)grid * 2 + 2), &part));
     ZK_TRY(host_staging(esz * 2, &host));
     void *res = (char *)part + esz * (size_t)grid * 2;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = stream ? (hipStream_t)stream : cur_stream();
     ZK_DISPATCH_FIELD(in->field, {
         fold_half_sums_kernel<F><<<grid, kBlock, 0, s>>>(in->dptr, out->dptr, q, load_host<F>(value), part);
         finish_sums_kernel<F><<<1, kBlock, 0, s>>>(part, (size_t)grid, 2, res);
@@ -398,7 +413,7 @@ static int tensor_impl(const zk_table *wb, const zk_table *wc, zk_table *out, vo
     size_t total = wb->len * wc->len;
     if (out->len < total) return ZK_E_ARG;
     ZK_TRY(require_device());
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = stream ? (hipStream_t)stream : cur_stream();
     if (mul) {
         ZK_DISPATCH_FIELD(wb->field, (tensor_kernel<F, true><<<grid_for(total), kBlock, 0, s>>>(wb->dptr, wc->dptr, out->dptr, wb->len)));
     } else {
@@ -434,7 +449,7 @@ int zk_mle_evaluate(const zk_table *t, const uint64_t *values, size_t nvalues, u
     int limbs = field_limbs64(t->field);
     size_t esz = (size_t)limbs * 8;
     if (nvalues == 0) {
-        ZK_HIP(hipMemcpy(out, t->dptr, esz, hipMemcpyDeviceToHost));
+        ZK_HIP(zk::memcpy_on_stream(out, t->dptr, esz, hipMemcpyDeviceToHost));
         return ZK_OK;
     }
     // ping-pong between two halves of one scratch allocation (len/2 + len/4 elements)
@@ -453,7 +468,7 @@ int zk_mle_evaluate(const zk_table *t, const uint64_t *values, size_t nvalues, u
         dst = nx;
     }
     if (rc == ZK_OK) {
-        hipError_t e = hipMemcpy(out, cur->dptr, esz, hipMemcpyDeviceToHost);
+        hipError_t e = zk::memcpy_on_stream(out, cur->dptr, esz, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
     }
     zk_table_free(a);

@@ -113,8 +113,8 @@ template <class F> int add_mul_mle(const zk_gate *g, size_t ngates, size_t layer
     size_t n = (size_t)1 << zk_num_of_layer_variables(layer_index);
     ZK_TRY(alloc_table(F::ID, n, add_i));
     ZK_TRY(alloc_table(F::ID, n, mul_i));
-    ZK_HIP(hipMemsetAsync(add_i->dptr, 0, n * 4 * F::N, nullptr));                     // vec![F::zero(); 2^vars] :133-134
-    ZK_HIP(hipMemsetAsync(mul_i->dptr, 0, n * 4 * F::N, nullptr));
+    ZK_HIP(hipMemsetAsync(add_i->dptr, 0, n * 4 * F::N, cur_stream()));                     // vec![F::zero(); 2^vars] :133-134
+    ZK_HIP(hipMemsetAsync(mul_i->dptr, 0, n * 4 * F::N, cur_stream()));
     std::vector<uint64_t> pa, pm;
     for (size_t k = 0; k < ngates; k++) {
         size_t pos = zk_wiring_index(layer_index, g[k].out, g[k].left, g[k].right);   // :139-155
@@ -126,10 +126,10 @@ template <class F> int add_mul_mle(const zk_gate *g, size_t ngates, size_t layer
         if (pos.empty()) continue;
         void *dpos;
         ZK_TRY(scratch(pos.size() * 8, &dpos));
-        ZK_HIP(hipMemcpy(dpos, pos.data(), pos.size() * 8, hipMemcpyHostToDevice));
-        scatter_one_kernel<F><<<grid_for(pos.size()), kBlock>>>((w ? mul_i : add_i)->dptr, (const uint64_t *)dpos, pos.size());
+        ZK_HIP(zk::memcpy_on_stream(dpos, pos.data(), pos.size() * 8, hipMemcpyHostToDevice));
+        scatter_one_kernel<F><<<grid_for(pos.size()), kBlock, 0, cur_stream()>>>((w ? mul_i : add_i)->dptr, (const uint64_t *)dpos, pos.size());
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipDeviceSynchronize());
+        ZK_HIP(hipStreamSynchronize(cur_stream()));
     }
     return ZK_OK;
 }

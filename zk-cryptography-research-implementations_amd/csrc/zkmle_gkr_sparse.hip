@@ -31,7 +31,7 @@ struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { pool_free(p); }                     // per-call scratch from the caching pool (context.h)
     int alloc(size_t bytes) { return pool_alloc(bytes, &p); }
-    int upload(const void *src, size_t bytes) { ZK_TRY(alloc(bytes)); if (bytes) ZK_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice)); return ZK_OK; }
+    int upload(const void *src, size_t bytes) { ZK_TRY(alloc(bytes)); if (bytes) ZK_HIP(zk::memcpy_on_stream(p, src, bytes, hipMemcpyHostToDevice)); return ZK_OK; }
 };
 template <class F> Fe<F> load_el(const uint64_t *src) { Fe<F> e; memcpy(e.l, src, 4 * F::N); return e; }
 template <class F> void store_el(uint64_t *dst, const Fe<F> &e) { memcpy(dst, e.l, 4 * F::N); }
@@ -184,11 +184,11 @@ template <class F> int evaluate_layers(std::vector<LayerDev> &layers, const uint
     for (size_t l = nl; l-- > 0;) {
         size_t nout = (size_t)1 << layers[l].out_bits;
         ZK_TRY(alloc_table(F::ID, nout, W[l]));
-        circuit_layer_kernel<F><<<blocks(nout), kBlock>>>(layers[l].arrays(), (const uint32_t *)layers[l].ord_out.p, (const uint32_t *)layers[l].st_out.p,
+        circuit_layer_kernel<F><<<blocks(nout), kBlock, 0, cur_stream()>>>(layers[l].arrays(), (const uint32_t *)layers[l].ord_out.p, (const uint32_t *)layers[l].st_out.p,
                                                            nout, W[l + 1]->dptr, W[l]->dptr);
         ZK_HIP(hipGetLastError());
     }
-    ZK_HIP(hipDeviceSynchronize());
+    ZK_HIP(hipStreamSynchronize(cur_stream()));
     return ZK_OK;
 }
 
@@ -232,7 +232,7 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         hipEvent_t e0, e1;
         ZK_HIP(hipEventCreate(&e0));
         ZK_HIP(hipEventCreate(&e1));
-        ZK_HIP(hipEventRecord(e0, nullptr));
+        ZK_HIP(hipEventRecord(e0, cur_stream()));
         LayerDev &Ly = layers[l];
         const uint32_t k = Ly.in_bits;
         const size_t nk = (size_t)1 << k, ng = Ly.ngates;
@@ -243,11 +243,11 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         ZK_TRY(w.alloc(ng * esz));
         if (l == 0) {
             ZK_TRY((eq_table<F>(ra.data(), Ly.out_bits, eqA)));
-            gate_weights_kernel<F><<<blocks(ng), kBlock>>>(Ly.arrays(), ng, eqA->dptr, nullptr, fe_zero<F>(), fe_zero<F>(), w.p);
+            gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>(Ly.arrays(), ng, eqA->dptr, nullptr, fe_zero<F>(), fe_zero<F>(), w.p);
         } else {
             ZK_TRY((eq_table<F>(rb.data(), Ly.out_bits, eqA)));
             ZK_TRY((eq_table<F>(rc.data(), Ly.out_bits, eqB)));
-            gate_weights_kernel<F><<<blocks(ng), kBlock>>>(Ly.arrays(), ng, eqA->dptr, eqB->dptr, load_el<F>(alpha), load_el<F>(beta), w.p);
+            gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>(Ly.arrays(), ng, eqA->dptr, eqB->dptr, load_el<F>(alpha), load_el<F>(beta), w.p);
         }
         ZK_HIP(hipGetLastError());
         // phase 1: W H1 + H0 * 1
@@ -255,9 +255,9 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         ZK_TRY(alloc_table(F::ID, nk, H1));
         ZK_TRY(alloc_table(F::ID, nk, H0));
         ZK_TRY(alloc_table(F::ID, nk, ones));
-        phase1_tables_kernel<F><<<blocks(nk), kBlock>>>(Ly.arrays(), (const uint32_t *)Ly.ord_left.p, (const uint32_t *)Ly.st_left.p, nk, w.p,
+        phase1_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(Ly.arrays(), (const uint32_t *)Ly.ord_left.p, (const uint32_t *)Ly.st_left.p, nk, w.p,
                                                          Wn->dptr, H1->dptr, H0->dptr);
-        fill_one_kernel<F><<<blocks(nk), kBlock>>>(ones->dptr, nk);
+        fill_one_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(ones->dptr, nk);
         ZK_HIP(hipGetLastError());
         memcpy(layer_claims + l * L64, claim, L64 * 8);
         tr.t.append_be<F>(load_el<F>(claim));                                        // sumcheck_gkr_protocol.rs:35
@@ -274,9 +274,9 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         ZK_TRY(alloc_table(F::ID, nk, M));
         ZK_TRY(alloc_table(F::ID, nk, upw));
         ZK_TRY(alloc_table(F::ID, nk, utw));
-        phase2_tables_kernel<F><<<blocks(nk), kBlock>>>(Ly.arrays(), (const uint32_t *)Ly.ord_right.p, (const uint32_t *)Ly.st_right.p, nk, w.p,
+        phase2_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(Ly.arrays(), (const uint32_t *)Ly.ord_right.p, (const uint32_t *)Ly.st_right.p, nk, w.p,
                                                          eqL->dptr, A->dptr, M->dptr);
-        uw_tables_kernel<F><<<blocks(nk), kBlock>>>(Wn->dptr, nk, load_el<F>(u), upw->dptr, utw->dptr);
+        uw_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(Wn->dptr, nk, load_el<F>(u), upw->dptr, utw->dptr);
         ZK_HIP(hipGetLastError());
         const zk_table *t2[4] = {A.get(), upw.get(), M.get(), utw.get()};
         ZK_TRY(zk_sumcheck_gkr_rounds(t2, 2, 2, &tr, lco + (size_t)k * 3 * L64, lch + (size_t)k * L64, fin));   // rounds over c
@@ -299,7 +299,7 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         }
         coff += (size_t)2 * k * 3;
         choff += (size_t)2 * k;
-        ZK_HIP(hipEventRecord(e1, nullptr));
+        ZK_HIP(hipEventRecord(e1, cur_stream()));
         ZK_HIP(hipEventSynchronize(e1));
         if (ms_layers) (void)hipEventElapsedTime(&ms_layers[l], e0, e1);
         (void)hipEventDestroy(e0);
@@ -321,17 +321,17 @@ template <class F> int wiring_eval(const zk_gate *g, size_t ngates, uint32_t out
     ZK_TRY((eq_table<F>(rc, in_bits, eqR)));
     DevBuf w;
     ZK_TRY(w.alloc(ngates * esz));
-    gate_weights_kernel<F><<<blocks(ngates), kBlock>>>(L.arrays(), ngates, eqA->dptr, pb ? eqB->dptr : nullptr,
+    gate_weights_kernel<F><<<blocks(ngates), kBlock, 0, cur_stream()>>>(L.arrays(), ngates, eqA->dptr, pb ? eqB->dptr : nullptr,
                                                         pb ? load_el<F>(alpha) : fe_zero<F>(), pb ? load_el<F>(beta) : fe_zero<F>(), w.p);
     int grid = reduce_grid_for(ngates);
     void *part;
     ZK_TRY(scratch(esz * ((size_t)grid * 2 + 2), &part));
     void *res = (char *)part + esz * (size_t)grid * 2;
-    wiring_eval_kernel<F><<<grid, kBlock>>>(L.arrays(), ngates, w.p, eqL->dptr, eqR->dptr, part);
-    finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, 2, res);
+    wiring_eval_kernel<F><<<grid, kBlock, 0, cur_stream()>>>(L.arrays(), ngates, w.p, eqL->dptr, eqR->dptr, part);
+    finish_sums_kernel<F><<<1, kBlock, 0, cur_stream()>>>(part, (size_t)grid, 2, res);
     ZK_HIP(hipGetLastError());
     uint64_t both[12];
-    ZK_HIP(hipMemcpy(both, res, esz * 2, hipMemcpyDeviceToHost));
+    ZK_HIP(zk::memcpy_on_stream(both, res, esz * 2, hipMemcpyDeviceToHost));
     memcpy(add_r, both, esz);
     memcpy(mul_r, both + F::N / 2, esz);
     return ZK_OK;
@@ -355,7 +355,7 @@ int circuit_evaluate_device(int field, const zk_gate *gates, const size_t *gate_
         for (size_t l = 0; l < nlayers; l++) goff[l + 1] = goff[l] + gate_counts[l];
         DevBuf dev;
         ZK_TRY(dev.alloc(eoff[nlayers + 1] * esz));
-        ZK_HIP(hipMemcpy((char *)dev.p + eoff[nlayers] * esz, inputs, widths[nlayers] * esz, hipMemcpyHostToDevice));
+        ZK_HIP(zk::memcpy_on_stream((char *)dev.p + eoff[nlayers] * esz, inputs, widths[nlayers] * esz, hipMemcpyHostToDevice));
         for (size_t l = nlayers; l-- > 0;) {
             size_t n = gate_counts[l], nout = widths[l], nin = widths[l + 1];
             std::vector<uint32_t> out(n), left(n), right(n), op(n), order, start;
@@ -373,12 +373,12 @@ int circuit_evaluate_device(int field, const zk_gate *gates, const size_t *gate_
             ZK_TRY(d_ord.upload(order.data(), n * 4));
             ZK_TRY(d_st.upload(start.data(), start.size() * 4));
             GateArrays ga{(const uint32_t *)d_out.p, (const uint32_t *)d_left.p, (const uint32_t *)d_right.p, (const uint32_t *)d_op.p};
-            circuit_layer_kernel<F><<<blocks(nout), kBlock>>>(ga, (const uint32_t *)d_ord.p, (const uint32_t *)d_st.p, nout,
+            circuit_layer_kernel<F><<<blocks(nout), kBlock, 0, cur_stream()>>>(ga, (const uint32_t *)d_ord.p, (const uint32_t *)d_st.p, nout,
                                                                (const char *)dev.p + eoff[l + 1] * esz, (char *)dev.p + eoff[l] * esz);
             ZK_HIP(hipGetLastError());
-            ZK_HIP(hipDeviceSynchronize());
+            ZK_HIP(hipStreamSynchronize(cur_stream()));
         }
-        ZK_HIP(hipMemcpy(evals, dev.p, eoff[nlayers + 1] * esz, hipMemcpyDeviceToHost));
+        ZK_HIP(zk::memcpy_on_stream(evals, dev.p, eoff[nlayers + 1] * esz, hipMemcpyDeviceToHost));
         (void)L64;
     });
     return ZK_OK;

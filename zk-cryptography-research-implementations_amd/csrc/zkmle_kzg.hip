@@ -56,7 +56,7 @@ struct Events {
     hipEvent_t e[8];
     int n = 0;
     ~Events() { for (int i = 0; i < n; i++) (void)hipEventDestroy(e[i]); }
-    int mark() { ZK_HIP(hipEventCreate(&e[n])); ZK_HIP(hipEventRecord(e[n], nullptr)); n++; return ZK_OK; }
+    int mark() { ZK_HIP(hipEventCreate(&e[n])); ZK_HIP(hipEventRecord(e[n], cur_stream())); n++; return ZK_OK; }
     float ms(int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, e[a], e[b]); return v; }
 };
 
@@ -123,17 +123,17 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     ZK_TRY(totals.alloc(nbuckets * 4));
     ZK_TRY(starts.alloc((nbuckets + 1) * 8));
     ZK_TRY(seg_starts.alloc((nbuckets + 2) * 4));
-    msm_digits_kernel<<<grid_for(n), kBlock>>>(d_scalars, n, (unsigned)c, nwin1, (uint16_t *)digits.p);
+    msm_digits_kernel<<<grid_for(n), kBlock, 0, cur_stream()>>>(d_scalars, n, (unsigned)c, nwin1, (uint16_t *)digits.p);
     ZK_HIP(hipGetLastError());
     ZK_TRY(ev.mark());
     // counting sort, bucket counters staged in LDS
     size_t lds_bytes = (size_t)nb * 4;
     ZK_HIP(hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     ZK_HIP(hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    msm_hist_kernel<<<nwin1 * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len, (uint32_t *)hist.p,
+    msm_hist_kernel<<<nwin1 * nchunks, kSortBlock, lds_bytes, cur_stream()>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len, (uint32_t *)hist.p,
                                                                  by_chunk);
     // per bucket set: exclusive prefix over the blocks that feed it (chunks of a window; or, shifted, the windows of a chunk)
-    msm_chunk_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock>>>((uint32_t *)hist.p, nwin, shifted ? nwin1 : nchunks, nb,
+    msm_chunk_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock, 0, cur_stream()>>>((uint32_t *)hist.p, nwin, shifted ? nwin1 : nchunks, nb,
                                                                                     (uint32_t *)totals.p);
     const uint32_t *d_totals = (const uint32_t *)totals.p;
     {
@@ -142,18 +142,18 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         ZK_TRY(te.alloc((size_t)ntiles * 8));
         ZK_TRY(ts.alloc((size_t)ntiles * 4));
         ZK_TRY(tm.alloc((size_t)ntiles * 4));
-        msm_scan_tiles_kernel<<<ntiles, kScanTile>>>(d_totals, nbuckets, seg_len, (uint64_t *)te.p, (uint32_t *)ts.p, (uint32_t *)tm.p);
-        msm_scan_tile_totals_kernel<<<1, 64>>>((uint64_t *)te.p, (uint32_t *)ts.p, (const uint32_t *)tm.p, ntiles, nbuckets,
+        msm_scan_tiles_kernel<<<ntiles, kScanTile, 0, cur_stream()>>>(d_totals, nbuckets, seg_len, (uint64_t *)te.p, (uint32_t *)ts.p, (uint32_t *)tm.p);
+        msm_scan_tile_totals_kernel<<<1, 64, 0, cur_stream()>>>((uint64_t *)te.p, (uint32_t *)ts.p, (const uint32_t *)tm.p, ntiles, nbuckets,
                                               (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
-        msm_scan_apply_kernel<<<ntiles, kScanTile>>>(d_totals, nbuckets, seg_len, (const uint64_t *)te.p, (const uint32_t *)ts.p,
+        msm_scan_apply_kernel<<<ntiles, kScanTile, 0, cur_stream()>>>(d_totals, nbuckets, seg_len, (const uint64_t *)te.p, (const uint32_t *)ts.p,
                                                      (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipDeviceSynchronize());
+        ZK_HIP(hipStreamSynchronize(cur_stream()));
     }
     uint64_t entries = 0;
     uint32_t tail[2] = {0, 0};                              // {segments, largest per-bucket segment count}
-    ZK_HIP(hipMemcpy(&entries, (uint64_t *)starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
-    ZK_HIP(hipMemcpy(tail, (uint32_t *)seg_starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
+    ZK_HIP(zk::memcpy_on_stream(&entries, (uint64_t *)starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
+    ZK_HIP(zk::memcpy_on_stream(tail, (uint32_t *)seg_starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
     uint32_t nseg = tail[0], max_segs = tail[1];
     ZK_TRY(sorted.alloc((entries ? entries : 1) * 4));
     if (!shifted && c >= 12 && n >= ((size_t)1 << 22)) {   // measured r1: wins at 2^24 (8.6 -> 5.4 ms), loses below 2^21
@@ -168,17 +168,17 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         ZK_TRY(poff.alloc((size_t)nwin * nh * pchunks * 8));
         ZK_TRY(part_e.alloc((entries ? entries : 1) * 4));
         ZK_TRY(part_l.alloc(entries ? entries : 1));
-        msm_part_hist_kernel<<<nwin * pchunks, 256>>>((const uint16_t *)digits.p, n, (unsigned)c, pchunks, pchunk_len, (uint32_t *)phist.p);
-        msm_part_scan_kernel<<<(unsigned)(((size_t)nwin * nh + 255) / 256), 256>>>((uint32_t *)phist.p, nwin, (unsigned)c, pchunks,
+        msm_part_hist_kernel<<<nwin * pchunks, 256, 0, cur_stream()>>>((const uint16_t *)digits.p, n, (unsigned)c, pchunks, pchunk_len, (uint32_t *)phist.p);
+        msm_part_scan_kernel<<<(unsigned)(((size_t)nwin * nh + 255) / 256), 256, 0, cur_stream()>>>((uint32_t *)phist.p, nwin, (unsigned)c, pchunks,
                                                                                   (const uint64_t *)starts.p, (uint64_t *)poff.p);
-        msm_part_scatter_kernel<<<nwin * pchunks, kPartBlock>>>((const uint16_t *)digits.p, n, (unsigned)c, pchunks, pchunk_len,
+        msm_part_scatter_kernel<<<nwin * pchunks, kPartBlock, 0, cur_stream()>>>((const uint16_t *)digits.p, n, (unsigned)c, pchunks, pchunk_len,
                                                                  (const uint64_t *)poff.p, (uint32_t *)part_e.p, (uint8_t *)part_l.p);
-        msm_fine_scatter_kernel<<<nwin * nh, kSortBlock>>>((const uint32_t *)part_e.p, (const uint8_t *)part_l.p, (unsigned)c,
+        msm_fine_scatter_kernel<<<nwin * nh, kSortBlock, 0, cur_stream()>>>((const uint32_t *)part_e.p, (const uint8_t *)part_l.p, (unsigned)c,
                                                            (const uint64_t *)starts.p, (uint32_t *)sorted.p);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipDeviceSynchronize());      // the intermediates are freed on scope exit
+        ZK_HIP(hipStreamSynchronize(cur_stream()));      // the intermediates are freed on scope exit
     } else {
-        msm_scatter_kernel<<<nwin1 * nchunks, kSortBlock, lds_bytes>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len,
+        msm_scatter_kernel<<<nwin1 * nchunks, kSortBlock, lds_bytes, cur_stream()>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len,
                                                                         (const uint32_t *)hist.p, (const uint64_t *)starts.p, (uint32_t *)sorted.p,
                                                                         by_chunk);
         ZK_HIP(hipGetLastError());
@@ -189,8 +189,8 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     size_t red_bytes = ((size_t)nwin << (c - 1)) * sizeof(G1Xyzz);
     ZK_TRY(A.alloc(red_bytes));
     ZK_TRY(R.alloc(red_bytes));
-    ZK_HIP(hipMemsetAsync(A.p, 0, red_bytes, nullptr));     // all-zero XYZZ = infinity (ZZ = 0)
-    if (c < 6) ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, nullptr));
+    ZK_HIP(hipMemsetAsync(A.p, 0, red_bytes, cur_stream()));     // all-zero XYZZ = infinity (ZZ = 0)
+    if (c < 6) ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, cur_stream()));
     if (nseg) {
         ZK_TRY(launch_msm_bucket_sum(d_bases, (const uint32_t *)sorted.p, (const uint64_t *)starts.p, (const uint32_t *)seg_starts.p,
                                      nbuckets, seg_len, nseg, partials.p, nullptr));
@@ -206,42 +206,42 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         ns.release();
         np.release();
         ZK_TRY(ns.alloc((nbuckets + 2) * 4));
-        msm_regroup_scan_kernel<<<1, kSortBlock>>>(cur_starts, nbuckets, kGroup, (uint32_t *)ns.p);
+        msm_regroup_scan_kernel<<<1, kSortBlock, 0, cur_stream()>>>(cur_starts, nbuckets, kGroup, (uint32_t *)ns.p);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipMemcpy(tail, (uint32_t *)ns.p + nbuckets, 8, hipMemcpyDeviceToHost));
+        ZK_HIP(zk::memcpy_on_stream(tail, (uint32_t *)ns.p + nbuckets, 8, hipMemcpyDeviceToHost));
         ZK_TRY(np.alloc(((size_t)tail[0] ? tail[0] : 1) * sizeof(G1Xyzz)));
-        ZK_TRY(launch_msm_partials_regroup(cur_partials, cur_starts, (const uint32_t *)ns.p, nbuckets, kGroup, tail[0], np.p, nullptr));
+        ZK_TRY(launch_msm_partials_regroup(cur_partials, cur_starts, (const uint32_t *)ns.p, nbuckets, kGroup, tail[0], np.p, cur_stream()));
         cur_partials = np.p;
         cur_starts = (const uint32_t *)ns.p;
         max_segs = tail[1];
     }
-    ZK_TRY(launch_msm_bucket_combine(cur_partials, cur_starts, nwin, (unsigned)c, A.p, nullptr));
+    ZK_TRY(launch_msm_bucket_combine(cur_partials, cur_starts, nwin, (unsigned)c, A.p, cur_stream()));
     ZK_TRY(ev.mark());
     std::vector<G1Xyzz> sums(nwin);
     if (c >= 6) {
         // two-stage weighted bucket sum (msm_reduce.hip): slot b = h L + l weighs b + 1 = L h + (l + 1)
         const unsigned cm1 = (unsigned)c - 1, k = cm1 / 2, hb = cm1 - k, mbits = hb > k ? hb : k;
-        ZK_HIP(hipMemcpyAsync(R.p, A.p, red_bytes, hipMemcpyDeviceToDevice, nullptr));      // the copy that reduces over l
+        ZK_HIP(hipMemcpyAsync(R.p, A.p, red_bytes, hipMemcpyDeviceToDevice, cur_stream()));      // the copy that reduces over l
         for (unsigned lvl = 0; lvl < mbits; lvl++) {
             size_t hh = lvl < hb ? ((size_t)1 << (hb - 1 - lvl)) : 0, lh = lvl < k ? ((size_t)1 << (k - 1 - lvl)) : 0;
-            ZK_TRY(launch_msm_plain_level(A.p, R.p, nwin, cm1, k, hh, lh, nullptr));
+            ZK_TRY(launch_msm_plain_level(A.p, R.p, nwin, cm1, k, hh, lh, cur_stream()));
         }
         DevBuf X, Y, out3;                                  // X: the arrays C (per window) then D, zero-padded; Y: their R arrays
         const size_t small_bytes = 2 * ((size_t)nwin << mbits) * sizeof(G1Xyzz);
         ZK_TRY(X.alloc(small_bytes));
         ZK_TRY(Y.alloc(small_bytes));
         ZK_TRY(out3.alloc(3 * (size_t)nwin * sizeof(G1Xyzz)));
-        ZK_HIP(hipMemsetAsync(Y.p, 0, small_bytes, nullptr));
-        ZK_TRY(launch_msm_gather_cd(A.p, R.p, nwin, cm1, k, mbits, X.p, nullptr));
+        ZK_HIP(hipMemsetAsync(Y.p, 0, small_bytes, cur_stream()));
+        ZK_TRY(launch_msm_gather_cd(A.p, R.p, nwin, cm1, k, mbits, X.p, cur_stream()));
         for (size_t half = (size_t)1 << (mbits - 1); half >= 1; half >>= 1) {   // 2 nwin problems of 2^mbits entries, 0-based weights
-            ZK_TRY(launch_msm_reduce_level(X.p, Y.p, 2 * nwin, mbits + 1, half, nullptr));
+            ZK_TRY(launch_msm_reduce_level(X.p, Y.p, 2 * nwin, mbits + 1, half, cur_stream()));
             if (half == 1) break;
         }
-        ZK_TRY(launch_msm_two_stage_out(X.p, Y.p, nwin, mbits, out3.p, nullptr));
+        ZK_TRY(launch_msm_two_stage_out(X.p, Y.p, nwin, mbits, out3.p, cur_stream()));
         std::vector<G1Xyzz> o(3 * (size_t)nwin);
-        ZK_HIP(hipMemcpyAsync(o.data(), out3.p, o.size() * sizeof(G1Xyzz), hipMemcpyDeviceToHost, nullptr));
+        ZK_HIP(hipMemcpyAsync(o.data(), out3.p, o.size() * sizeof(G1Xyzz), hipMemcpyDeviceToHost, cur_stream()));
         ZK_TRY(ev.mark());
-        ZK_HIP(hipDeviceSynchronize());
+        ZK_HIP(hipStreamSynchronize(cur_stream()));
         for (unsigned w = 0; w < nwin; w++) {               // S_w = 2^k sum_h h D[h] + (sum_l l C[l] + sum_l C[l])
             G1Xyzz hi = o[3 * (size_t)w + 2];
             for (unsigned i = 0; i < k; i++) hi = g1_dbl(hi);
@@ -250,15 +250,15 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     } else {
         // c - 1 halving levels over the 2^(c-1) slots of every window, in place; window sum = R[0] + A[0]
         for (size_t half = (size_t)1 << (c - 2); half >= 1; half >>= 1) {
-            ZK_TRY(launch_msm_reduce_level(A.p, R.p, nwin, (unsigned)c, half, nullptr));
+            ZK_TRY(launch_msm_reduce_level(A.p, R.p, nwin, (unsigned)c, half, cur_stream()));
             if (half == 1) break;
         }
         DevBuf wsums;
         ZK_TRY(wsums.alloc((size_t)nwin * sizeof(G1Xyzz)));
-        ZK_TRY(launch_msm_window_sums(A.p, R.p, nwin, (unsigned)c, wsums.p, nullptr));
-        ZK_HIP(hipMemcpyAsync(sums.data(), wsums.p, (size_t)nwin * sizeof(G1Xyzz), hipMemcpyDeviceToHost, nullptr));
+        ZK_TRY(launch_msm_window_sums(A.p, R.p, nwin, (unsigned)c, wsums.p, cur_stream()));
+        ZK_HIP(hipMemcpyAsync(sums.data(), wsums.p, (size_t)nwin * sizeof(G1Xyzz), hipMemcpyDeviceToHost, cur_stream()));
         ZK_TRY(ev.mark());
-        ZK_HIP(hipDeviceSynchronize());
+        ZK_HIP(hipStreamSynchronize(cur_stream()));
     }
     if (shifted) {                                          // the shifts live in the bases: bucket set j IS MSM j
         for (unsigned j = 0; j < batch; j++) result[j] = sums[j];
@@ -303,7 +303,7 @@ int bases_u(const zk_g1_bases *b, const void **out) {
     if (!mb->dptr_u) {
         void *d = nullptr;
         ZK_HIP(hipMalloc(&d, b->n * kBaseUBytes));
-        int rc = launch_g1_bases_to_u(b->dptr, b->n, d, nullptr);
+        int rc = launch_g1_bases_to_u(b->dptr, b->n, d, cur_stream());
         if (rc != ZK_OK) { (void)hipFree(d); return rc; }
         mb->dptr_u = d;
     }
@@ -314,8 +314,8 @@ int bases_u(const zk_g1_bases *b, const void **out) {
 // XYZZ (device) -> affine bases (device)
 int normalize_to_bases(const void *d_xyzz, size_t n, zk_g1_bases **out) {
     ZK_TRY(bases_alloc(n, out));
-    ZK_TRY(launch_batch_to_affine(d_xyzz, n, (*out)->dptr, nullptr));
-    ZK_HIP(hipDeviceSynchronize());
+    ZK_TRY(launch_batch_to_affine(d_xyzz, n, (*out)->dptr, cur_stream()));
+    ZK_HIP(hipStreamSynchronize(cur_stream()));
     return ZK_OK;
 }
 
@@ -353,7 +353,7 @@ int generator_table(const void **out) {
         }
         void *d = nullptr;
         ZK_HIP(hipMalloc(&d, aff.size() * sizeof(G1Affine)));
-        ZK_HIP(hipMemcpy(d, aff.data(), aff.size() * sizeof(G1Affine), hipMemcpyHostToDevice));
+        ZK_HIP(zk::memcpy_on_stream(d, aff.data(), aff.size() * sizeof(G1Affine), hipMemcpyHostToDevice));
         g_gen_table[dev] = d;
     }
     *out = g_gen_table[dev];
@@ -367,7 +367,7 @@ int lagrange_basis_device(const uint64_t *taus, size_t ntaus, zk_table **out) {
     ZK_TRY(zk_table_alloc(ZK_FR381, n, &t));
     EqBuilder<Fr381> eb;                                          // variable 0 = MSB (:36); outer products of half tables
     int rc = eb.build(taus, (uint32_t)ntaus, t->dptr);
-    if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = ZK_E_HIP;
+    if (rc == ZK_OK && hipStreamSynchronize(cur_stream()) != hipSuccess) rc = ZK_E_HIP;
     if (rc != ZK_OK) { zk_table_free(t); return rc; }
     *out = t;
     return ZK_OK;
@@ -381,13 +381,13 @@ int zk_g1_bases_upload(const uint64_t *affine, size_t n, zk_g1_bases **out) {
     if (!affine || !out || n == 0) return ZK_E_ARG;
     ZK_TRY(require_device());
     ZK_TRY(bases_alloc(n, out));
-    hipError_t e = hipMemcpy((*out)->dptr, affine, n * sizeof(G1Affine), hipMemcpyHostToDevice);
+    hipError_t e = zk::memcpy_on_stream((*out)->dptr, affine, n * sizeof(G1Affine), hipMemcpyHostToDevice);
     if (e != hipSuccess) { zk_g1_bases_free(*out); *out = nullptr; ZK_HIP(e); }
     return ZK_OK;
 }
 int zk_g1_bases_download(const zk_g1_bases *b, uint64_t *affine) {
     if (!b || !affine) return ZK_E_ARG;
-    ZK_HIP(hipMemcpy(affine, b->dptr, b->n * sizeof(G1Affine), hipMemcpyDeviceToHost));
+    ZK_HIP(zk::memcpy_on_stream(affine, b->dptr, b->n * sizeof(G1Affine), hipMemcpyDeviceToHost));
     return ZK_OK;
 }
 int zk_g1_bases_free(zk_g1_bases *b) {
@@ -429,7 +429,7 @@ int zk_g1_bases_synthetic(size_t n, const uint64_t *a_fr, const uint64_t *d_fr, 
     G1Affine dstep = g1_to_affine(g1_mul_canonical(g, d.l, 8));
     DevBuf xyzz;
     ZK_TRY(xyzz.alloc(n * sizeof(G1Xyzz)));
-    ZK_TRY(launch_synthetic_bases(g, dstep, a, d, n, 64, xyzz.p, nullptr));
+    ZK_TRY(launch_synthetic_bases(g, dstep, a, d, n, 64, xyzz.p, cur_stream()));
     return normalize_to_bases(xyzz.p, n, out);
 }
 
@@ -461,7 +461,7 @@ int zk_kzg_setup_g1(const uint64_t *taus, size_t ntaus, zk_g1_bases **out) {
     int rc = generator_table(&table);
     if (rc == ZK_OK) rc = xyzz.alloc(n * sizeof(G1Xyzz));
     if (rc == ZK_OK) {
-        rc = launch_fixed_base_mul(basis->dptr, n, table, xyzz.p, nullptr);   // :51-60
+        rc = launch_fixed_base_mul(basis->dptr, n, table, xyzz.p, cur_stream());   // :51-60
     }
     if (rc == ZK_OK) rc = normalize_to_bases(xyzz.p, n, out);
     zk_table_free(basis);
@@ -489,7 +489,7 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
         DevBuf xyzz;
         rc = xyzz.alloc(half * sizeof(G1Xyzz));
         if (rc != ZK_OK) break;
-        rc = launch_g1_pair_add(cur->dptr, half, xyzz.p, nullptr);
+        rc = launch_g1_pair_add(cur->dptr, half, xyzz.p, cur_stream());
         if (rc != ZK_OK) break;
         rc = normalize_to_bases(xyzz.p, half, &key->level[t]);
         cur = key->level[t];
@@ -508,15 +508,15 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
         for (size_t j = 0; j < nlev && rc == ZK_OK && e == hipSuccess; j++) {
             const zk_g1_bases *lv = key->level[key->small_t0 + j];
             const size_t off = ((size_t)1 << nlev) - ((size_t)1 << (nlev - j));
-            e = hipMemcpyAsync((char *)aff.p + off * sizeof(G1Affine), lv->dptr, lv->n * sizeof(G1Affine), hipMemcpyDeviceToDevice, nullptr);
+            e = hipMemcpyAsync((char *)aff.p + off * sizeof(G1Affine), lv->dptr, lv->n * sizeof(G1Affine), hipMemcpyDeviceToDevice, cur_stream());
         }
         if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
         for (unsigned w = 0; w < nwin && rc == ZK_OK; w++) {
-            rc = launch_g1_bases_to_u(aff.p, total, (char *)key->small_u + (size_t)w * total * kBaseUBytes, nullptr);
-            if (rc == ZK_OK && w + 1 < nwin) rc = launch_g1_shift(aff.p, total, c, xyzz.p, nullptr);
-            if (rc == ZK_OK && w + 1 < nwin) rc = launch_batch_to_affine(xyzz.p, total, aff.p, nullptr);
+            rc = launch_g1_bases_to_u(aff.p, total, (char *)key->small_u + (size_t)w * total * kBaseUBytes, cur_stream());
+            if (rc == ZK_OK && w + 1 < nwin) rc = launch_g1_shift(aff.p, total, c, xyzz.p, cur_stream());
+            if (rc == ZK_OK && w + 1 < nwin) rc = launch_batch_to_affine(xyzz.p, total, aff.p, cur_stream());
         }
-        if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = ZK_E_HIP;
+        if (rc == ZK_OK && hipStreamSynchronize(cur_stream()) != hipSuccess) rc = ZK_E_HIP;
     }
     if (rc != ZK_OK) { zk_kzg_opening_key_free(key.release()); return rc; }
     *out = key.release();
@@ -564,7 +564,7 @@ int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg
         // batched level j = t - small_t0 sits at offset 2^nlev - 2^(nlev - j) of the end-to-end scalar buffer
         void *qdst = small ? (void *)((char *)smallq.p + (((size_t)1 << nlev) - ((size_t)1 << (nlev - (t - key->small_t0)))) * 32) : q->dptr;
         // quotient = hi half - lo half (compute_quotient_polynomial :165-179)
-        elementwise_kernel<Fr381, OP_HI_MINUS_LO><<<grid_for(half), kBlock>>>(sub->dptr, nullptr, qdst, half, fe_zero<Fr381>());
+        elementwise_kernel<Fr381, OP_HI_MINUS_LO><<<grid_for(half), kBlock, 0, cur_stream()>>>(sub->dptr, nullptr, qdst, half, fe_zero<Fr381>());
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; break; }
         if (!small) {

@@ -57,10 +57,10 @@ template <class F> int absorb_table(Transcript &t, const void *dptr, size_t len)
     for (size_t off = 0, k = 0; off < len && rc == ZK_OK; off += chunk, k++) {
         const int b = (int)(k & 1);
         const size_t n = len - off < chunk ? len - off : chunk;
-        elementwise_kernel<F, OP_TO_CANONICAL_BE><<<grid_for(n), kBlock>>>((const char *)dptr + off * esz, nullptr, tmp[b].p, n, fe_zero<F>());
+        elementwise_kernel<F, OP_TO_CANONICAL_BE><<<grid_for(n), kBlock, 0, cur_stream()>>>((const char *)dptr + off * esz, nullptr, tmp[b].p, n, fe_zero<F>());
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(host[b], tmp[b].p, n * esz, hipMemcpyDeviceToHost, nullptr);
-        if (e == hipSuccess) e = hipEventRecord(ev[b], nullptr);
+        if (e == hipSuccess) e = hipMemcpyAsync(host[b], tmp[b].p, n * esz, hipMemcpyDeviceToHost, cur_stream());
+        if (e == hipSuccess) e = hipEventRecord(ev[b], cur_stream());
         if (e == hipSuccess && pending >= 0) {                        // hash the previous chunk while this one is in flight
             e = hipEventSynchronize(ev[pending]);
             if (e == hipSuccess) t.append((const uint8_t *)host[pending], pending_n * esz);
@@ -74,14 +74,14 @@ template <class F> int absorb_table(Transcript &t, const void *dptr, size_t len)
         if (e == hipSuccess) t.append((const uint8_t *)host[pending], pending_n * esz);
         else { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
     }
-    (void)hipDeviceSynchronize();
+    (void)hipStreamSynchronize(cur_stream());
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
     return rc;
 }
 
 template <class F> int download_elems(const void *d, size_t n, Fe<F> *out) {
-    ZK_HIP(hipMemcpy(out, d, n * 4 * F::N, hipMemcpyDeviceToHost));
+    ZK_HIP(zk::memcpy_on_stream(out, d, n * 4 * F::N, hipMemcpyDeviceToHost));
     return ZK_OK;
 }
 
@@ -108,7 +108,7 @@ template <class F> struct DeviceRounds {
         tr.sponge().export_state(sp.a, &sp.fill);
         memcpy(host.data(), &sp, sizeof sp);
         if (nbasis) memcpy(host.data() + kHead, basis_flat.data(), nbasis * 4 * F::N);
-        ZK_HIP(hipMemcpy(buf.p, host.data(), host.size(), hipMemcpyHostToDevice));
+        ZK_HIP(zk::memcpy_on_stream(buf.p, host.data(), host.size(), hipMemcpyHostToDevice));
         return ZK_OK;
     }
     RoundCtx ctx(int npts, int mode) const { return RoundCtx{npts, mode, sponge(), basis(), proof()}; }
@@ -119,7 +119,7 @@ template <class F> struct DeviceRounds {
         a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
         size_t threads = (count + 63) / 64 * 64;          // one partial per lane up to 1024 lanes
         if (threads > (size_t)kFinishBlock) threads = kFinishBlock;
-        sumcheck_finish_kernel<F><<<1, (int)threads>>>(a);
+        sumcheck_finish_kernel<F><<<1, (int)threads, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
@@ -129,16 +129,16 @@ template <class F> struct DeviceRounds {
         TailArgs a{};
         a.tabs = tabs; a.buf[0] = buf0; a.buf[1] = buf1; a.nprod = nprod; a.ntab = nprod * nfac; a.len = len;
         a.ctx = ctx(nfac + 1, mode); a.round = round; a.msg_base = msg_base; a.chal_base = chal_base; a.per = per; a.fin_slot = fin_slot;
-        if (nfac == 1) sumcheck_tail_kernel<F, 1><<<1, kTailBlock>>>(a);
-        else if (nfac == 2) sumcheck_tail_kernel<F, 2><<<1, kTailBlock>>>(a);
-        else sumcheck_tail_kernel<F, 3><<<1, kTailBlock>>>(a);
+        if (nfac == 1) sumcheck_tail_kernel<F, 1><<<1, kTailBlock, 0, cur_stream()>>>(a);
+        else if (nfac == 2) sumcheck_tail_kernel<F, 2><<<1, kTailBlock, 0, cur_stream()>>>(a);
+        else sumcheck_tail_kernel<F, 3><<<1, kTailBlock, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
     // the single synchronisation of the sumcheck: proof slots + sponge back to the host
     int collect(Transcript &tr) {
         host.resize(bytes());
-        ZK_HIP(hipMemcpy(host.data(), buf.p, bytes(), hipMemcpyDeviceToHost));
+        ZK_HIP(zk::memcpy_on_stream(host.data(), buf.p, bytes(), hipMemcpyDeviceToHost));
         DevSponge sp;
         memcpy(&sp, host.data(), sizeof sp);
         tr.sponge().import_state(sp.a, sp.fill);
@@ -181,7 +181,7 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
     {   // round-0 half sums (split_polynomial_and_sum_each :74-89); claimed sum = their sum (:28), absorbed first (:40-41)
         size_t seg = len / 2;
         int grid = reduce_grid_for(seg);
-        segment_sums_kernel<F><<<grid, kBlock>>>(table->dptr, seg, 2, part);
+        segment_sums_kernel<F><<<grid, kBlock, 0, cur_stream()>>>(table->dptr, seg, 2, part);
         ZK_HIP(hipGetLastError());
         ZK_TRY(dr.launch_finish(part, (size_t)grid, 2, 0, 1, 0, 1, 3));               // :50-58 of round 0
     }
@@ -193,7 +193,7 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
         const void *rp = dr.slot_ptr(3 + 3 * (size_t)round);           // this round's challenge (:58), on the device
         size_t q = cl / 4;                                             // :61-63 fused with the next round's :50
         int grid = reduce_grid_for(q);
-        fold_half_sums_kernel<F><<<grid, kBlock>>>(cur, dst, q, fe_zero<F>(), part, rp);
+        fold_half_sums_kernel<F><<<grid, kBlock, 0, cur_stream()>>>(cur, dst, q, fe_zero<F>(), part, rp);
         ZK_HIP(hipGetLastError());
         ZK_TRY(dr.launch_finish(part, (size_t)grid, 2, 0, 0, 0, 1 + 3 * (size_t)(round + 1), 3 + 3 * (size_t)(round + 1)));
         cur = dst;
@@ -259,17 +259,17 @@ int check_sumpoly(const zk_table *const *tables, size_t nprod, size_t nfac) {
 }
 
 template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t half, void *part, int grid) {
-    if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock>>>(tabs, nprod, half, part);
-    else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock>>>(tabs, nprod, half, part);
-    else round_evals_kernel<F, 3><<<grid, kBlock>>>(tabs, nprod, half, part);
+    if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
+    else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
+    else round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
 template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t q, const Fe<F> &r, void *part, int grid,
                                                const void *rp = nullptr) {
-    if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock>>>(tabs, nprod, q, r, part, rp);
-    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock>>>(tabs, nprod, q, r, part, rp);
-    else fold_round_evals_kernel<F, 3><<<grid, kBlock>>>(tabs, nprod, q, r, part, rp);
+    if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
+    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
+    else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -287,9 +287,9 @@ template <class F> int round_evals(const zk_table *const *tables, size_t nprod, 
     ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
     void *res = (char *)part + esz * (size_t)grid * npts;
     ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
-    finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, (int)npts, res);
+    finish_sums_kernel<F><<<1, kBlock, 0, cur_stream()>>>(part, (size_t)grid, (int)npts, res);
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpy(out, res, esz * npts, hipMemcpyDeviceToHost));
+    ZK_HIP(zk::memcpy_on_stream(out, res, esz * npts, hipMemcpyDeviceToHost));
     return ZK_OK;
 }
 
@@ -323,7 +323,7 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
     unsigned nvars = ilog2(len);                                       // :29
     if (nvars == 0) {
         if (final_values)
-            for (size_t k = 0; k < ntab; k++) ZK_HIP(hipMemcpy(final_values + k * L64, tables[k]->dptr, esz, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < ntab; k++) ZK_HIP(zk::memcpy_on_stream(final_values + k * L64, tables[k]->dptr, esz, hipMemcpyDeviceToHost));
         return ZK_OK;
     }
     DevBuf bufA, bufB;
@@ -440,7 +440,7 @@ template <class F> struct RoundsImpl : RoundsBase {
     int to_limbs(void *part, int grid, uint64_t *limbs) {
         size_t threads = ((size_t)grid + 63) / 64 * 64;
         if (threads > (size_t)kFinishBlock) threads = kFinishBlock;
-        partials_to_limbs_kernel<F><<<1, (int)threads>>>(part, (size_t)grid, (int)npts, limbs);
+        partials_to_limbs_kernel<F><<<1, (int)threads, 0, cur_stream()>>>(part, (size_t)grid, (int)npts, limbs);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
@@ -475,7 +475,7 @@ template <class F> struct RoundsImpl : RoundsBase {
             ZK_TRY(to_limbs(part, grid, limbs));
         } else {                                                         // 2 entries -> 1: nothing left to evaluate
             for (size_t k = 0; k < ntab; k++) {
-                fold_kernel<F><<<1, 64>>>(tabs.in[k], tabs.out[k], 1, 0, fe_zero<F>(), rp);
+                fold_kernel<F><<<1, 64, 0, cur_stream()>>>(tabs.in[k], tabs.out[k], 1, 0, fe_zero<F>(), rp);
                 ZK_HIP(hipGetLastError());
             }
         }
@@ -487,7 +487,7 @@ template <class F> struct RoundsImpl : RoundsBase {
         LimbsFinishArgs a{};
         a.limbs = limbs; a.ctx = dr.ctx((int)npts, mode); a.with_claim = (mode == 0 && round == 0) ? 1 : 0;
         a.claim_slot = 0; a.msg_slot = msg_base + per * round; a.chal_slot = chal_base + per * round;
-        limbs_finish_kernel<F><<<1, 64>>>(a);
+        limbs_finish_kernel<F><<<1, 64, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
         round++;
         return ZK_OK;
@@ -636,9 +636,9 @@ int zk_sumpoly_fold_round_evals(const zk_table *const *in, zk_table *const *out,
         ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
         void *res = (char *)part + esz * (size_t)grid * npts;
         ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, load_el<F>(value), part, grid)));
-        finish_sums_kernel<F><<<1, kBlock>>>(part, (size_t)grid, (int)npts, res);
+        finish_sums_kernel<F><<<1, kBlock, 0, cur_stream()>>>(part, (size_t)grid, (int)npts, res);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipMemcpy(out_evals, res, esz * npts, hipMemcpyDeviceToHost));
+        ZK_HIP(zk::memcpy_on_stream(out_evals, res, esz * npts, hipMemcpyDeviceToHost));
     });
     for (size_t k = 0; k < nprod * nfac; k++) out[k]->len = len / 2;
     return ZK_OK;
@@ -651,7 +651,7 @@ int zk_sumpoly_reduce(const zk_table *const *tables, size_t nprod, size_t nfac, 
     SumPolyTables tabs{};
     for (size_t k = 0; k < nprod * nfac; k++) tabs.in[k] = tables[k]->dptr;
     size_t len = tables[0]->len;
-    ZK_DISPATCH_FIELD(tables[0]->field, (sumpoly_reduce_kernel<F><<<grid_for(len), kBlock>>>(tabs, (int)nprod, (int)nfac, len, out->dptr)));
+    ZK_DISPATCH_FIELD(tables[0]->field, (sumpoly_reduce_kernel<F><<<grid_for(len), kBlock, 0, cur_stream()>>>(tabs, (int)nprod, (int)nfac, len, out->dptr)));
     ZK_HIP(hipGetLastError());
     out->len = len;
     return ZK_OK;
