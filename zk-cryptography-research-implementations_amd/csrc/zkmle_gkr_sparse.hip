@@ -142,27 +142,79 @@ void group_by(const std::vector<uint32_t> &key, size_t nbins, std::vector<uint32
     std::vector<uint32_t> cur(start.begin(), start.end() - 1);
     for (size_t i = 0; i < key.size(); i++) order[cur[key[i]]++] = (uint32_t)i;
 }
-int upload_layer(const zk_gate *g, size_t n, uint32_t out_bits, uint32_t in_bits, LayerDev &L) {
-    std::vector<uint32_t> out(n), left(n), right(n), op(n);
-    for (size_t i = 0; i < n; i++) {
-        if ((g[i].out >> out_bits) || (g[i].left >> in_bits) || (g[i].right >> in_bits) || g[i].op > 1) return ZK_E_RANGE;
-        out[i] = (uint32_t)g[i].out; left[i] = (uint32_t)g[i].left; right[i] = (uint32_t)g[i].right; op[i] = (uint32_t)g[i].op;
+// ---- circuit compile on the device: split the gate records, then three counting sorts (by left / right / output index) -----
+// The order of the gates inside a group does not matter: the tables built from it are sums in the field, exact and commutative.
+__global__ void split_gates_kernel(const zk_gate *__restrict__ g, size_t n, uint32_t out_bits, uint32_t in_bits, uint32_t *__restrict__ out,
+                                   uint32_t *__restrict__ left, uint32_t *__restrict__ right, uint32_t *__restrict__ op, int *__restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    zk_gate x = g[i];
+    if ((x.out >> out_bits) || (x.left >> in_bits) || (x.right >> in_bits) || x.op > 1) { *bad = 1; x.out = x.left = x.right = x.op = 0; }
+    out[i] = (uint32_t)x.out; left[i] = (uint32_t)x.left; right[i] = (uint32_t)x.right; op[i] = (uint32_t)x.op;
+}
+__global__ void key_hist_kernel(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ counts) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&counts[key[i]], 1u);
+}
+// exclusive scan of counts[0 .. nbins) in place, counts[nbins] = total: one workgroup, each lane owns a contiguous run
+__global__ void __launch_bounds__(1024) exclusive_scan_kernel(uint32_t *__restrict__ counts, size_t nbins) {
+    __shared__ uint32_t sh[1024];
+    const size_t per = (nbins + 1023) / 1024, lo = (size_t)threadIdx.x * per, hi = lo + per < nbins ? lo + per : nbins;
+    uint32_t sum = 0;
+    for (size_t i = lo; i < hi; i++) sum += counts[i];
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (unsigned off = 1; off < 1024; off <<= 1) {       // inclusive scan of the 1024 run totals
+        uint32_t v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
     }
+    uint32_t run = sh[threadIdx.x] - sum;
+    for (size_t i = lo; i < hi; i++) { uint32_t c = counts[i]; counts[i] = run; run += c; }
+    if (threadIdx.x == 1023) counts[nbins] = sh[1023];
+}
+__global__ void key_scatter_kernel(const uint32_t *__restrict__ key, size_t n, const uint32_t *__restrict__ start, uint32_t *__restrict__ cursor,
+                                   uint32_t *__restrict__ order) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k = key[i];
+    order[start[k] + atomicAdd(&cursor[k], 1u)] = (uint32_t)i;
+}
+inline unsigned blocks(size_t n);
+int group_by_device(const uint32_t *d_key, size_t n, size_t nbins, DevBuf &order, DevBuf &start) {
+    DevBuf cursor;
+    ZK_TRY(order.alloc((n ? n : 1) * 4));
+    ZK_TRY(start.alloc((nbins + 1) * 4));
+    ZK_TRY(cursor.alloc(nbins * 4));
+    ZK_HIP(hipMemsetAsync(start.p, 0, (nbins + 1) * 4, cur_stream()));
+    ZK_HIP(hipMemsetAsync(cursor.p, 0, nbins * 4, cur_stream()));
+    if (n) key_hist_kernel<<<blocks(n), kBlock, 0, cur_stream()>>>(d_key, n, (uint32_t *)start.p);
+    exclusive_scan_kernel<<<1, 1024, 0, cur_stream()>>>((uint32_t *)start.p, nbins);
+    if (n) key_scatter_kernel<<<blocks(n), kBlock, 0, cur_stream()>>>(d_key, n, (const uint32_t *)start.p, (uint32_t *)cursor.p, (uint32_t *)order.p);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(cur_stream()));           // `cursor` goes back to the pool
+    return ZK_OK;
+}
+int upload_layer(const zk_gate *g, size_t n, uint32_t out_bits, uint32_t in_bits, LayerDev &L) {
     L.ngates = n; L.out_bits = out_bits; L.in_bits = in_bits;
-    ZK_TRY(L.out.upload(out.data(), n * 4));
-    ZK_TRY(L.left.upload(left.data(), n * 4));
-    ZK_TRY(L.right.upload(right.data(), n * 4));
-    ZK_TRY(L.op.upload(op.data(), n * 4));
-    std::vector<uint32_t> order, start;
-    group_by(left, (size_t)1 << in_bits, order, start);
-    ZK_TRY(L.ord_left.upload(order.data(), n * 4));
-    ZK_TRY(L.st_left.upload(start.data(), start.size() * 4));
-    group_by(right, (size_t)1 << in_bits, order, start);
-    ZK_TRY(L.ord_right.upload(order.data(), n * 4));
-    ZK_TRY(L.st_right.upload(start.data(), start.size() * 4));
-    group_by(out, (size_t)1 << out_bits, order, start);
-    ZK_TRY(L.ord_out.upload(order.data(), n * 4));
-    ZK_TRY(L.st_out.upload(start.data(), start.size() * 4));
+    DevBuf raw, bad;
+    ZK_TRY(raw.upload(g, (n ? n : 1) * sizeof(zk_gate)));
+    ZK_TRY(bad.alloc(4));
+    ZK_HIP(hipMemsetAsync(bad.p, 0, 4, cur_stream()));
+    ZK_TRY(L.out.alloc((n ? n : 1) * 4));
+    ZK_TRY(L.left.alloc((n ? n : 1) * 4));
+    ZK_TRY(L.right.alloc((n ? n : 1) * 4));
+    ZK_TRY(L.op.alloc((n ? n : 1) * 4));
+    if (n) split_gates_kernel<<<blocks(n), kBlock, 0, cur_stream()>>>((const zk_gate *)raw.p, n, out_bits, in_bits, (uint32_t *)L.out.p, (uint32_t *)L.left.p,
+                                                                      (uint32_t *)L.right.p, (uint32_t *)L.op.p, (int *)bad.p);
+    ZK_HIP(hipGetLastError());
+    int flag = 0;
+    ZK_HIP(zk::memcpy_on_stream(&flag, bad.p, 4, hipMemcpyDeviceToHost));
+    if (flag) return ZK_E_RANGE;                             // index panic in the reference
+    ZK_TRY(group_by_device((const uint32_t *)L.left.p, n, (size_t)1 << in_bits, L.ord_left, L.st_left));
+    ZK_TRY(group_by_device((const uint32_t *)L.right.p, n, (size_t)1 << in_bits, L.ord_right, L.st_right));
+    ZK_TRY(group_by_device((const uint32_t *)L.out.p, n, (size_t)1 << out_bits, L.ord_out, L.st_out));
     return ZK_OK;
 }
 
