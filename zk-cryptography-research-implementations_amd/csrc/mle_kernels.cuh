@@ -87,6 +87,30 @@ template <class F> __global__ void fold0_kernel(const void *__restrict__ in, voi
     fe_store<F>(out, i, fe_add<F>(y1, mr.times(fe_sub<F>(y2, y1))));
 }
 
+// evaluate()'s last folds in ONE launch: a table of <= 2 * kEvalTailBlock entries is folded by up to kEvalTailVars successive
+// values by one workgroup (level 0 reads `in`, writes `tmp`; later levels fold `tmp` in place: thread i only overwrites the entry
+// it alone reads).  A chain of 11 tiny launches is ~60 us of pure launch latency otherwise.
+constexpr int kEvalTailBlock = 1024;
+constexpr int kEvalTailVars = 11;
+template <class F> struct EvalTailValues {
+    Fe<F> r[kEvalTailVars];
+};
+template <class F> __global__ void __launch_bounds__(kEvalTailBlock) evaluate_tail_kernel(const void *__restrict__ in, void *__restrict__ tmp, size_t len,
+                                                                                            EvalTailValues<F> vals, int nvals) {
+    const void *src = in;
+    for (int k = 0; k < nvals; k++) {
+        const size_t half = len >> 1;
+        if (threadIdx.x < half) {
+            const Multiplier<F> mr(vals.r[k]);
+            Fe<F> y1 = fe_load<F>(src, threadIdx.x), y2 = fe_load<F>(src, threadIdx.x + half);
+            fe_store<F>(tmp, threadIdx.x, fe_add<F>(y1, mr.times(fe_sub<F>(y2, y1))));
+        }
+        __syncthreads();
+        src = tmp;
+        len = half;
+    }
+}
+
 // ---- reductions ------------------------------------------------------------------------------------
 // Sums are accumulated LAZILY: a Wide is the plain integer sum (N + 1 limbs: up to 2^32 terms below 2^(32 N)), one
 // carry chain per addition (N + 1 VALU ops instead of ~35 for a modular addition with its conditional subtraction),

@@ -460,6 +460,18 @@ int zk_mle_evaluate(const zk_table *t, const uint64_t *values, size_t nvalues, u
     const zk_table *cur = t;
     zk_table *dst = a, *other = b;
     for (size_t i = 0; i < nvalues && rc == ZK_OK; i++) {
+        if (cur->len <= 2 * (size_t)kEvalTailBlock && nvalues - i <= (size_t)kEvalTailVars) {   // the rest in one launch
+            const int nv = (int)(nvalues - i);
+            ZK_DISPATCH_FIELD(t->field, {
+                EvalTailValues<F> vals;
+                for (int k = 0; k < kEvalTailVars; k++) vals.r[k] = k < nv ? load_host<F>(values + (i + k) * limbs) : fe_zero<F>();
+                evaluate_tail_kernel<F><<<1, kEvalTailBlock, 0, cur_stream()>>>(cur->dptr, dst->dptr, cur->len, vals, nv);
+            });
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
+            cur = dst;
+            break;
+        }
         dst->len = cur->len / 2;
         rc = zk_mle_fold_ptr(t->field, cur->dptr, cur->len, 0, values + i * limbs, dst->dptr, nullptr);
         cur = dst;
