@@ -289,3 +289,44 @@ def test_two_host_threads_prove_concurrently(zk):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_full_size_provers_size_independent_properties(zk):
+    """BASELINE config 5 sizes, where the oracle is too slow to run: a 2^24 basic sumcheck proof passes the verifier's round
+    equations (p_k(0) + p_k(1) = previous claim, verifier.rs:47-64) recomputed here on the host with the oracle's field
+    arithmetic, its last claim equals the table's evaluation at the challenges (:67-70, GPU evaluate cross-checked by a
+    second, unfused fold chain), and a tampered round is rejected.  Same for a GKR sumcheck on 4 tables of 2^22."""
+    field = 0
+    p = O.modulus(field)
+    poly = zk.MultilinearPolynomial.random(field, 1 << 24, 0x5EED0005)
+    prover = zk.Prover.init(field, poly)
+    proof = prover.prove()
+    rp = [zk.to_ints(field, r) for r in proof.round_univariate_polynomials]
+    claim = zk.to_ints(field, proof.initial_claimed_sum)[0]
+    ch = zk.to_ints(field, prover.challenges)
+    assert len(rp) == 24
+    for (e0, e1), r in zip(rp, ch):
+        assert (e0 + e1) % p == claim
+        claim = (e0 + r * (e1 - e0)) % p
+    assert zk.to_ints(field, poly.evaluate(prover.challenges))[0] == claim
+    cur = poly                                                     # the same evaluation through 24 separate fold launches
+    for r in prover.challenges:
+        cur = zk.MultilinearPolynomial.partial_evaluate(cur, 0, r)
+    assert zk.to_ints(field, cur.evaluated_values)[0] == claim
+    assert zk.Verifier.init().verify(proof) is True
+    bad = proof.round_univariate_polynomials.copy()
+    bad[7, 0, 0] ^= np.uint64(1)
+    assert zk.Verifier.init().verify(zk.sumcheck.SumcheckProof(proof.initial_polynomial, proof.initial_claimed_sum, bad)) is False
+    del poly, proof, prover, cur
+    n = 1 << 22
+    tabs = [[zk.MultilinearPolynomial.random(field, n, 0x5EED0400 + 2 * q + f) for f in range(2)] for q in range(2)]
+    sp = zk.SumPolynomial([zk.ProductPolynomial(t) for t in tabs])
+    claimed = sp.add_polynomials_element_wise().sum()
+    res = zk.sumcheck.prove(sp, claimed, zk.Transcript())
+    v = zk.sumcheck.verify(res, zk.Transcript(), field)
+    assert v.is_proof_valid and np.array_equal(v.last_claimed_sum, sp.evaluate(res.random_challenges))
+    co = res.round_univariate_polynomials.copy()
+    co[3, 1, 0] ^= np.uint64(1)
+    bad = zk.sumcheck.SumcheckProverProof(res.claimed_sum, co, res.random_challenges)
+    assert not zk.sumcheck.verify(bad, zk.Transcript(), field).is_proof_valid
