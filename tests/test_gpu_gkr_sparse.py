@@ -102,3 +102,31 @@ def test_wide_circuits_verify(zk, bits):
     if len(tampered.wb_evals):
         tampered.wb_evals[0, 0] ^= np.uint64(1)
         assert zk.gkr.sparse_verify(f, rows, out_bits, tampered, x) is False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wiring", ["random", "regular"])
+def test_config4_shape_prove_verify_2p18(zk, wiring):
+    """BASELINE config 4's shape (depth 3, same width per layer, 2^18 gates per layer here, both wirings of SURVEY 8d), beyond
+    what the dense oracle can hold: the proof passes the sparse verifier (sumcheck equations + the wiring predicate evaluated
+    independently on the device), the compiled-circuit path gives the same proof, and a flipped coefficient is rejected."""
+    field, lg, depth = 0, 18, 3
+    n = 1 << lg
+    rng = np.random.default_rng(0x5EED0004)
+    rows, out_bits = [], []
+    for _ in range(depth):
+        g = np.zeros((n, 4), np.uint64)
+        if wiring == "random":
+            g[:, 0] = rng.integers(0, n, n); g[:, 1] = rng.integers(0, n, n)
+        else:
+            g[:, 0] = (2 * np.arange(n)) % n; g[:, 1] = (2 * np.arange(n) + 1) % n
+        g[:, 2] = np.arange(n); g[:, 3] = rng.integers(0, 2, n)
+        rows.append(g); out_bits.append(lg)
+    x = zk.MultilinearPolynomial.random(field, n, 0x5EED0004).evaluated_values
+    proof = zk.gkr.sparse_prove(field, rows, out_bits, x)
+    assert zk.gkr.sparse_verify(field, rows, out_bits, proof, x)
+    circuit = zk.gkr.SparseCircuit(rows, out_bits, n)
+    again = zk.gkr.sparse_prove(field, None, None, x, circuit=circuit)
+    assert np.array_equal(again.coeffs, proof.coeffs) and np.array_equal(again.challenges, proof.challenges)
+    proof.coeffs[5, 1, 0] ^= np.uint64(1)
+    assert not zk.gkr.sparse_verify(field, rows, out_bits, proof, x)
