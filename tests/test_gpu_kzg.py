@@ -213,3 +213,33 @@ def test_commit_open_random_n10(zk):
         assert O.g1_affine_ints(proof.proofs[i]) == M.g1_mul(M.G1, q_tau), i
         acc = (acc + q_tau * (taus_i[i] - opening_i[i])) % R
     assert acc == (f_tau - v) % R
+
+
+def test_msm_config5_size_2p24(zk):
+    """BASELINE config 5: the 2^24-term MSM, checked with the O(N) linear identity for bases [a + i d] G; the two field sums
+    over 16.7M scalars are taken with vectorised 16-bit-piece arithmetic on the canonical limbs (exact)."""
+    from zkmle_amd import _lib as L
+    n = 1 << 24
+    a, d = rand_fr(zk, 2, 24)
+    bases = zk.G1Bases.synthetic(n, a, d)
+    scalars = zk.MultilinearPolynomial.random(0, n, 0x5EED0003)
+    got, stats = zk.kzg.msm(scalars, bases, with_stats=True)
+    assert stats["window_bits"] == 16 and stats["terms"] == n and stats["windows"] == 16
+    mont = scalars.evaluated_values
+    canon = np.zeros_like(mont)
+    L.check(L.lib().zk_vec_to_canonical(0, L.p64(mont), n, L.p64(canon)))
+    idx = np.arange(n, dtype=np.uint64)
+    s_sum, is_sum = 0, 0
+    step = 1 << 20
+    for k in range(4):
+        for j in range(4):
+            piece = (canon[:, k] >> np.uint64(16 * j)) & np.uint64(0xFFFF)
+            shift = 64 * k + 16 * j
+            s_sum += int(piece.sum(dtype=np.uint64)) << shift                   # < 2^40
+            acc = 0
+            for lo in range(0, n, step):                                        # 2^20 terms below 2^40 each: < 2^60
+                acc += int((idx[lo:lo + step] * piece[lo:lo + step]).sum(dtype=np.uint64))
+            is_sum += acc << shift
+    ai, di = O.to_ints(O.FR381, np.stack([a, d]))
+    k = (ai * s_sum + di * is_sum) % R
+    assert O.g1_affine_ints(got) == M.g1_mul(M.G1, k)
