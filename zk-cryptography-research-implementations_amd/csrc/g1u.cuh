@@ -94,7 +94,7 @@ __device__ __forceinline__ void g1u_madd(G1XyzzU &acc, G1AffineU q, bool neg) {
         }
     }
     FqU x3 = usub<F>(uadd<F>(usqr<F>(rn), pppn), uadd<F>(qq, qq));
-    FqU y3 = uadd<F>(umul<F>(rn, usub<F>(x3, qq)), umul<F>(acc.y, pppn));
+    FqU y3 = umul2<F>(rn, usub<F>(x3, qq), acc.y, pppn);      // one reduction for the two products
     acc.zzz = usub<F>(u_zero<F>(), umul<F>(acc.zzz, pppn));
     acc.zz = zz3;
     acc.x = x3;

@@ -201,6 +201,21 @@ template <class F> ZK_HD Ufe<F> umul(const Ufe<F> &a, const Ufe<F> &b) {
     for (int i = 0; i < L; i++) u_row<F>(T, a, b.l[i]);
     return u_normalize_columns<F>(T);
 }
+// (a1 * b1 + a2 * b2) / 2^(29 L) mod p with ONE Montgomery reduction per row: 3 L^2 multiply-adds instead of 4 L^2 for two
+// products.  All four operands normalized (limbs < 2^29): a live column then collects at most L * 3 * 2^58 < 2^64.
+template <class F> ZK_HD Ufe<F> umul2(const Ufe<F> &a1, const Ufe<F> &b1, const Ufe<F> &a2, const Ufe<F> &b2) {
+    constexpr int L = UParams<F>::L;
+    uint64_t T[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) T[j] = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+#pragma unroll
+        for (int j = 0; j < L; j++) T[j] += (uint64_t)a1.l[j] * b1.l[i];
+        u_row<F>(T, a2, b2.l[i]);
+    }
+    return u_normalize_columns<F>(T);
+}
 // a^2 / 2^(29 L): the row scan with the symmetric products taken once.  At step t the live column j holds
 // absolute weight j + t, so a_j a_t (j > t) is added doubled at step t only; every contribution to the column
 // that the Montgomery step consumes (weight t) comes from steps <= t/2, so T[0] is complete when it is used.
