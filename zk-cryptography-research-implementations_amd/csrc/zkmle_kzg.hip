@@ -111,10 +111,14 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
     if (shifted) { chunk_len = 0; nchunks = batch; }        // chunk j = MSM j = bucket set j (msm_chunk_range)
     const unsigned by_chunk = shifted ? batch : 0u;
-    // one lane per bucket SEGMENT: cap the serial chain so that ~2^20 lanes exist whatever the window
-    // size (measured r1: 2^20 terms, c = 14: 149k lanes -> 0.7e9 add/s; 521k lanes at c = 16 -> 2.1e9 add/s)
-    size_t seg_target = ((size_t)n * nwin1) >> 20;
-    unsigned seg_len = (unsigned)(seg_target < 16 ? 16 : seg_target);
+    // one lane per bucket SEGMENT: cap the serial chain so that ~2^22 lanes exist whatever the window size, at least 16 points
+    // per lane.  Measured r1 after the bucket update became the unsaturated dual-product form (2^24 terms, bucket phase, ms;
+    // lanes 0.8M / 1.3M / 2.4M / 4.4M / 8.6M / 17M): 58.7 / 49.4 / 43.6 / 41.4 / 43.4 / 44.7; minimum 4 / 8 / 16 / 32 points per lane
+    // at 2^20 terms: 4.13 / 3.59 / 3.50 / 3.81.  ZK_MSM_SEG_SHIFT / ZK_MSM_SEG_MIN override, for measurements.
+    static const int seg_shift = [] { const char *e = getenv("ZK_MSM_SEG_SHIFT"); int k = e ? atoi(e) : 22; return k < 10 ? 10 : (k > 24 ? 24 : k); }();
+    size_t seg_target = ((size_t)n * nwin1) >> seg_shift;
+    static const unsigned seg_min = [] { const char *e = getenv("ZK_MSM_SEG_MIN"); int k = e ? atoi(e) : 16; return (unsigned)(k < 2 ? 2 : k); }();
+    unsigned seg_len = (unsigned)(seg_target < seg_min ? seg_min : seg_target);
     Events ev;
     ZK_TRY(ev.mark());
     DevBuf digits, hist, totals, starts, seg_starts, sorted, partials, A, R;
