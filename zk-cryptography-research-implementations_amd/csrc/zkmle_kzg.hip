@@ -160,7 +160,10 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     ZK_HIP(zk::memcpy_on_stream(tail, (uint32_t *)seg_starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
     uint32_t nseg = tail[0], max_segs = tail[1];
     ZK_TRY(sorted.alloc((entries ? entries : 1) * 4));
-    if (!shifted && c >= 12 && n >= ((size_t)1 << 22)) {   // measured r1: wins at 2^24 (8.6 -> 5.4 ms), loses below 2^21
+    static const int two_level_bits = [] { const char *e = getenv("ZK_MSM_TWO_LEVEL_BITS"); int k = e ? atoi(e) : 20; return k < 12 ? 12 : k; }();
+    // measured r1 (sort phase, ms, one-level / two-level): 2^18 0.17 / 0.39, 2^19 0.35 / 0.37, 2^20 0.57 / 0.44, 2^21 0.91 / 0.63,
+    // 2^24 8.6 / 3.5
+    if (!shifted && c >= 12 && n >= ((size_t)1 << two_level_bits)) {
         // two-level scatter: partition by the high bits of the bucket id (tile-sorted whole-run writes), then finish
         // each 256-bucket partition with one workgroup (msm_kernels.cuh)
         const unsigned lb = (unsigned)(c - 1) < kFineBits ? (unsigned)(c - 1) : kFineBits, nh = 1u << (c - 1 - lb);
@@ -177,7 +180,8 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
                                                                                   (const uint64_t *)starts.p, (uint64_t *)poff.p);
         msm_part_scatter_kernel<<<nwin * pchunks, kPartBlock, 0, cur_stream()>>>((const uint16_t *)digits.p, n, (unsigned)c, pchunks, pchunk_len,
                                                                  (const uint64_t *)poff.p, (uint32_t *)part_e.p, (uint8_t *)part_l.p);
-        msm_fine_scatter_kernel<<<nwin * nh, kSortBlock, 0, cur_stream()>>>((const uint32_t *)part_e.p, (const uint8_t *)part_l.p, (unsigned)c,
+        ZK_HIP(hipFuncSetAttribute((const void *)msm_fine_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFineLdsBytes));
+        msm_fine_scatter_kernel<<<nwin * nh, kSortBlock, kFineLdsBytes, cur_stream()>>>((const uint32_t *)part_e.p, (const uint8_t *)part_l.p, (unsigned)c,
                                                            (const uint64_t *)starts.p, (uint32_t *)sorted.p);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipStreamSynchronize(cur_stream()));      // the intermediates are freed on scope exit
