@@ -244,8 +244,8 @@ __global__ void msm_scatter_kernel(const uint16_t *__restrict__ digits, size_t n
 // partition (a contiguous range of 256 buckets, ~0.5 MB of entries) is finished by one workgroup whose 256 open
 // runs stay L2-resident.  A partition occupies the same index range in the intermediate and in the final array.
 constexpr unsigned kFineBits = 8;
-constexpr int kPartTile = 2048;      // elements per LDS tile
-constexpr int kPartBlock = 256;
+constexpr int kPartTile = 8192;      // elements per LDS tile
+constexpr int kPartBlock = 1024;
 
 // A1: phist[(w * nh + h) * nchunks + chunk] = entries of chunk whose bucket has high part h
 __global__ void msm_part_hist_kernel(const uint16_t *__restrict__ digits, size_t n, unsigned c, unsigned nchunks, size_t chunk_len,
