@@ -1,6 +1,8 @@
-// zkmle_sumcheck.hip -- C ABI: transcript, basic sumcheck prover/verifier, SumPolynomial kernels and
-// the GKR sumcheck prover/verifier.  Tables stay in HBM; the host runs only the O(rounds)
-// control path (Keccak transcript, 3-point interpolation).
+// zkmle_sumcheck.hip -- C ABI: transcript, basic sumcheck prover/verifier, SumPolynomial kernels, the GKR sumcheck
+// prover/verifier and the device-resident rounds handle (zk_rounds_*) of the sharded provers.  Tables stay in HBM.  The host
+// absorbs the table-sized transcript input (pipelined with the GPU's byte conversion) and hands the sponge to the device;
+// every round -- reduction, round message, Keccak absorb + sample, challenge, fold -- then runs there (dev_transcript.cuh),
+// with one synchronisation per sumcheck.
 #include <string.h>
 
 #include <chrono>
