@@ -119,6 +119,9 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     size_t seg_target = ((size_t)n * nwin1) >> seg_shift;
     static const unsigned seg_min = [] { const char *e = getenv("ZK_MSM_SEG_MIN"); int k = e ? atoi(e) : 16; return (unsigned)(k < 2 ? 2 : k); }();
     unsigned seg_len = (unsigned)(seg_target < seg_min ? seg_min : seg_target);
+    // the batched pass feeds a bucket from every window: the largest level's buckets hold ~16 * 2^19 / 2^15 = 256 entries, and
+    // 16-entry segments would put them just over the 16-partials-per-bucket limit of the combine kernel (an extra 1.3 ms regroup)
+    if (shifted && seg_len < 2 * seg_min) seg_len = 2 * seg_min;
     Events ev;
     ZK_TRY(ev.mark());
     DevBuf digits, hist, totals, starts, seg_starts, sorted, partials, A, R;
