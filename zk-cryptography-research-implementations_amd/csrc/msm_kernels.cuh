@@ -59,15 +59,28 @@ __global__ void msm_digits_kernel(const void *__restrict__ scalars, size_t n, un
 // pass 1: per (chunk, window) histogram in LDS -> hist[(w * nchunks + chunk) * nb + b]
 // `by_chunk`: the output slot of block (w, chunk) is (chunk, w) instead of (w, chunk): every chunk is a bucket set of its
 // own that ALL windows feed (batched MSMs on window-shifted bases, zkmle_kzg.hip msm_core)
-// `by_chunk` = g > 0 additionally makes the chunks the halving ranges of a KZG opening's levels laid end to end:
-// chunk j = [2^g - 2^(g-j), +2^(g-1-j)), g = by_chunk (chunk_len is ignored).
-__device__ __forceinline__ void msm_chunk_range(unsigned chunk, size_t chunk_len, size_t n, unsigned by_chunk, size_t &lo, size_t &hi) {
-    if (by_chunk) {
-        lo = ((size_t)1 << by_chunk) - ((size_t)1 << (by_chunk - chunk));
-        hi = lo + ((size_t)1 << (by_chunk - 1 - chunk));
-    } else {
+// `by_chunk` = g > 0: the digit stream is the g halving levels of a KZG opening laid end to end (level j = 2^(g-1-j) entries
+// from 2^g - 2^(g-j)), every level is a bucket set of its own, and the chunks are: 2^kSubBits-entry pieces of the levels that
+// have at least that many entries (so the big levels spread over many workgroups), then one chunk per smaller level.
+constexpr unsigned kSubBits = 15;   // measured r1 (2^20 opening, scatter + scan, ms): 13 -> 1.07, 15 -> 0.38, 16 -> 0.45; one chunk per level 0.93
+__device__ __host__ inline unsigned msm_geo_nbig(unsigned g) { return g > kSubBits ? (1u << (g - kSubBits)) - 1u : 0u; }
+__device__ __host__ inline unsigned msm_geo_nchunks(unsigned g) { return msm_geo_nbig(g) + (g < kSubBits ? g : kSubBits); }
+__device__ __forceinline__ void msm_chunk_range(unsigned chunk, size_t chunk_len, size_t n, unsigned by_chunk, size_t &lo, size_t &hi, unsigned &set) {
+    if (!by_chunk) {
         lo = (size_t)chunk * chunk_len;
         hi = lo + chunk_len < n ? lo + chunk_len : n;
+        set = 0;
+        return;
+    }
+    const unsigned g = by_chunk, nbig = msm_geo_nbig(g);
+    if (chunk < nbig) {
+        lo = (size_t)chunk << kSubBits;
+        hi = lo + ((size_t)1 << kSubBits);
+        set = g - (64u - (unsigned)__clzll((long long)((((size_t)1 << g) - lo) - 1)));      // g - ceil(log2(2^g - lo))
+    } else {
+        set = (g > kSubBits ? g - kSubBits : 0u) + (chunk - nbig);
+        lo = ((size_t)1 << g) - ((size_t)1 << (g - set));
+        hi = lo + ((size_t)1 << (g - 1 - set));
     }
 }
 __global__ void msm_hist_kernel(const uint16_t *__restrict__ digits, size_t n, unsigned c, unsigned nchunks,
@@ -78,7 +91,8 @@ __global__ void msm_hist_kernel(const uint16_t *__restrict__ digits, size_t n, u
     for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = 0;
     __syncthreads();
     size_t lo, hi;
-    msm_chunk_range(chunk, chunk_len, n, by_chunk, lo, hi);
+    unsigned set;
+    msm_chunk_range(chunk, chunk_len, n, by_chunk, lo, hi, set);
     const uint16_t *d = digits + (size_t)w * n;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         unsigned enc = d[i];
@@ -99,6 +113,26 @@ __global__ void msm_chunk_scan_kernel(uint32_t *__restrict__ hist, unsigned nwin
     uint32_t run = 0;
     for (unsigned ch = 0; ch < nchunks; ch++) {
         uint32_t *p = hist + ((size_t)w * nchunks + ch) * nb + b;
+        uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    totals[id] = run;
+}
+
+// pass 2a for the level layout (by_chunk = g): bucket set j is fed by the rows (chunk, w) of level j's chunks, which are
+// contiguous: exclusive prefix over them (in place) and the bucket total
+__global__ void msm_set_scan_kernel(uint32_t *__restrict__ hist, unsigned g, unsigned nwin1, unsigned nb, uint32_t *__restrict__ totals) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)g * nb) return;
+    unsigned j = id / nb, b = id % nb;
+    const unsigned nbig = msm_geo_nbig(g), jb = g > kSubBits ? g - kSubBits : 0u;
+    size_t chunk_lo, cnt;
+    if (j < jb) { chunk_lo = (((size_t)1 << g) - ((size_t)1 << (g - j))) >> kSubBits; cnt = (size_t)1 << (g - 1 - j - kSubBits); }
+    else { chunk_lo = nbig + (j - jb); cnt = 1; }
+    uint32_t run = 0;
+    for (size_t r = chunk_lo * nwin1; r < (chunk_lo + cnt) * nwin1; r++) {
+        uint32_t *p = hist + r * nb + b;
         uint32_t v = *p;
         *p = run;
         run += v;
@@ -222,9 +256,10 @@ __global__ void msm_scatter_kernel(const uint16_t *__restrict__ digits, size_t n
     for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = off[b];
     __syncthreads();
     size_t lo, hi;
-    msm_chunk_range(chunk, chunk_len, n, by_chunk, lo, hi);
+    unsigned set;
+    msm_chunk_range(chunk, chunk_len, n, by_chunk, lo, hi, set);
     const uint16_t *d = digits + (size_t)w * n;
-    const uint64_t *st = starts + (size_t)(by_chunk ? chunk : w) * nb;
+    const uint64_t *st = starts + (size_t)(by_chunk ? set : w) * nb;
     const size_t base = by_chunk ? (size_t)w * n : 0;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         unsigned enc = d[i];

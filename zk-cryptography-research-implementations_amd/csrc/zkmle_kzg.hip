@@ -109,7 +109,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     size_t chunk_len = (n + 15) / 16;
     if (chunk_len < 4096) chunk_len = 4096;
     unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
-    if (shifted) { chunk_len = 0; nchunks = batch; }        // chunk j = MSM j = bucket set j (msm_chunk_range)
+    if (shifted) { chunk_len = 0; nchunks = msm_geo_nchunks(batch); }   // pieces of the levels; level j = bucket set j (msm_chunk_range)
     const unsigned by_chunk = shifted ? batch : 0u;
     // one lane per bucket SEGMENT: cap the serial chain so that ~2^22 lanes exist whatever the window size, at least 16 points
     // per lane.  Measured r1 after the bucket update became the unsaturated dual-product form (2^24 terms, bucket phase, ms;
@@ -139,9 +139,12 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     ZK_HIP(hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     msm_hist_kernel<<<nwin1 * nchunks, kSortBlock, lds_bytes, cur_stream()>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len, (uint32_t *)hist.p,
                                                                  by_chunk);
-    // per bucket set: exclusive prefix over the blocks that feed it (chunks of a window; or, shifted, the windows of a chunk)
-    msm_chunk_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock, 0, cur_stream()>>>((uint32_t *)hist.p, nwin, shifted ? nwin1 : nchunks, nb,
-                                                                                    (uint32_t *)totals.p);
+    // per bucket set: exclusive prefix over the blocks that feed it (the chunks of a window; or, shifted, every (chunk, window) of a level)
+    if (shifted)
+        msm_set_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock, 0, cur_stream()>>>((uint32_t *)hist.p, batch, nwin1, nb, (uint32_t *)totals.p);
+    else
+        msm_chunk_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock, 0, cur_stream()>>>((uint32_t *)hist.p, nwin, nchunks, nb,
+                                                                                                     (uint32_t *)totals.p);
     const uint32_t *d_totals = (const uint32_t *)totals.p;
     {
         unsigned ntiles = (unsigned)((nbuckets + kScanTile - 1) / kScanTile);
