@@ -84,6 +84,16 @@ def test_g2_generator_and_arithmetic():
         assert g2_from(out) == M.g2_add(x, y)
 
 
+def test_pairing_golden_vectors(derived_kats):
+    """the committed GT values (tests/golden/derived_kats.json, made with oracle/pairing_model.py) pin the product's pairing"""
+    k = derived_kats["pairing"]
+    want = [(int(c0, 16), int(c1, 16)) for c0, c1 in k["e_g1_g2"]]
+    assert c_pairing(M.G1, M.G2) == want
+    a, b = int(k["a"], 16), int(k["b"], 16)
+    want2 = [(int(c0, 16), int(c1, 16)) for c0, c1 in k["e_aG1_bG2"]]
+    assert c_pairing(M.g1_mul(M.G1, a), M.g2_mul(M.G2, b)) == want2
+
+
 def test_pairing_equals_the_model_and_is_bilinear():
     e = c_pairing(M.G1, M.G2)
     assert e == M.pairing(M.G1, M.G2)                      # same element of GT from two different algorithms
