@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 OPS = {"add": 0, "mul": 1}
 
 
-@pytest.mark.parametrize("world,logn", [(1, 3), (2, 1), (2, 2), (2, 10), (4, 2), (4, 9), (2, 14)])
+@pytest.mark.parametrize("world,logn", [(1, 3), (2, 1), (2, 2), (2, 10), (4, 2), (4, 9), (2, 14), (2, 17)])
 def test_sharded_provers_on_gpu(world, logn):
     field = O.FR381
     n = 1 << logn

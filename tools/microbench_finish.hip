@@ -16,11 +16,11 @@ int main(int argc, char **argv) {
     size_t count = argc > 1 ? atol(argv[1]) : 256; int npts = 3;
     void *part, *buf;
     CK(hipMalloc(&part, 32 * count * 4)); CK(hipMemset(part, 1, 32 * count * 4));
-    int threads = (int)((count + 63) / 64 * 64); if (threads > kFinishBlock) threads = kFinishBlock;
+    int threads = (int)((count + 63) / 64 * 64); if (threads > kFinishBlock - 64) threads = kFinishBlock - 64; threads += 64;   // + the helper wave
     CK(hipMalloc(&buf, 4096)); CK(hipMemset(buf, 0, 4096));
     FinishArgs a{};
     a.partials = part; a.count = count; a.ctx.npts = npts; a.ctx.mode = 1; a.with_claim = 0;
-    a.ctx.sponge = (DevSponge *)buf; a.ctx.basis = (char *)buf + 256; a.ctx.proof = (char *)buf + 1024; a.msg_slot = 0; a.chal_slot = 3;
+    a.ctx.sponge = (DevSponge *)buf; a.ctx.basis = (char *)buf + 256; a.ctx.proof = (char *)buf + 1024; a.flags = kDerive1; a.prev_msg_slot = 8; a.prev_chal_slot = 11; a.msg_slot = 0; a.chal_slot = 3;
     for (int it = 0; it < 5; it++) {
         sumcheck_finish_kernel<F><<<1, threads>>>(a);
         CK(hipDeviceSynchronize());

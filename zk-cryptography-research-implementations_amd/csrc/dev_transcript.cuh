@@ -158,10 +158,30 @@ struct RoundCtx {
                              // npts^2 coefficients as canonical integers (ev * canonical = canonical product)
     void *proof;             // Fe slots
 };
+// The evaluation at 1 comes for free: the round polynomial the prover sent last satisfies p_k(r_k) = e_{k+1}(0) + e_{k+1}(1)
+// identically (both sides are the sum over the folded table), whatever sum was claimed from outside.  A producer that skips
+// the products of the point 1 (fold_round_evals_kernel, `skip1`) leaves ev[1] to be derived as p_k(r_k) - ev[0]; p_k(r_k) is
+// re-evaluated from the previous round's proof slots by a spare wave while the other waves reduce the partials, so it costs
+// no time (d products), against one product per pair index saved in the producer.  Same field elements as evaluating the
+// point 1 directly.
+enum { kDerive1 = 1 };
+// previous round's message evaluated at its challenge (one lane)
+template <class F> __device__ __forceinline__ Fe<F> previous_claim(const RoundCtx &c, size_t prev_msg_slot, size_t prev_chal_slot) {
+    const Fe<F> r = fe_load<F>(c.proof, prev_chal_slot);
+    if (c.mode == 0) {
+        Fe<F> e0 = fe_load<F>(c.proof, prev_msg_slot), e1 = fe_load<F>(c.proof, prev_msg_slot + 1);
+        return fe_add<F>(e0, fe_mul<F>(r, fe_sub<F>(e1, e0)));
+    }
+    Fe<F> nc = fe_load<F>(c.proof, prev_msg_slot + c.npts - 1);
+#pragma unroll 1
+    for (int d = c.npts - 2; d >= 0; d--) nc = fe_add<F>(fe_mul<F>(nc, r), fe_load<F>(c.proof, prev_msg_slot + d));
+    return nc;
+}
 
 template <class F> struct RoundShared {                      // LDS of the transcript step
     Fe<F> ev[kMaxPts];
     Fe<F> pr[2 * kMaxPts * kMaxPts];
+    Fe<F> claim;
     Fe<F> chal;
     uint32_t msg[(kMaxPts + 1) * F::N + 8];
     uint64_t st[25], cl[25], tmp[25];
@@ -171,9 +191,13 @@ template <class F> struct RoundShared {                      // LDS of the trans
 // the proof slots, absorbs it, samples; the challenge goes to proof[chal_slot] and to S.chal.
 template <class F>
 __device__ __forceinline__ void round_message_and_challenge(RoundShared<F> &S, const RoundCtx &c, int with_claim, size_t claim_slot,
-                                                            size_t msg_slot, size_t chal_slot, uint32_t &fill, unsigned lane) {
+                                                            size_t msg_slot, size_t chal_slot, uint32_t &fill, unsigned lane, int flags = 0) {
     const int npts = c.npts;
     const int nmsg = npts + (with_claim ? 1 : 0);
+    if (flags & kDerive1) {                                  // S.claim was left by the helper wave / lane (see kDerive1)
+        if (lane == 0) S.ev[1] = fe_sub<F>(S.claim, S.ev[0]);
+        wave_lds_sync();
+    }
     if (c.mode == 0) {
         if ((int)lane < nmsg) {
             const int t = (int)lane;
@@ -222,7 +246,9 @@ struct FinishArgs {
     size_t count;
     RoundCtx ctx;
     int with_claim;          // mode 0, round 0: absorb evals[0] + evals[1] first (prover.rs:28,40-41)
+    int flags;               // kDerive1: the block carries one extra wave that evaluates the previous round's message
     size_t claim_slot, msg_slot, chal_slot;
+    size_t prev_msg_slot, prev_chal_slot;   // kDerive1
 };
 
 // One workgroup (64..1024 lanes, a multiple of 64).  Stage 1: every wave reduces its share of the partials, all npts
@@ -232,20 +258,26 @@ template <class F>
 __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArgs a) {
     __shared__ Wide<F> sh[kMaxPts * 16];                     // [t * 16 + wave]
     __shared__ RoundShared<F> S;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // with kDerive1 the last wave is the helper: it evaluates the previous round's message at its challenge meanwhile
+    const unsigned nwaves = (blockDim.x >> 6) - ((a.flags & kDerive1) ? 1u : 0u), nred = nwaves << 6;
     const int npts = a.ctx.npts;
     TS(0);
-    Wide<F> acc[kMaxPts];                                    // lazy sums (mle_kernels.cuh); unused ones stay zero
+    if (wave == nwaves) {                                    // helper wave (only present with kDerive1)
+        if (lane == 0) S.claim = previous_claim<F>(a.ctx, a.prev_msg_slot, a.prev_chal_slot);
+    } else {
+        Wide<F> acc[kMaxPts];                                // lazy sums (mle_kernels.cuh); unused ones stay zero
 #pragma unroll
-    for (int t = 0; t < kMaxPts; t++) {
-        acc[t] = wide_zero<F>();
-        if (t < npts)
-            for (size_t i = tid; i < a.count; i += blockDim.x) wide_add_fe<F>(acc[t], fe_load<F>(a.partials, (size_t)t * a.count + i));
-    }
-    wave_reduce_wide<F, kMaxPts>(acc, npts);
-    if (lane == 63) {
+        for (int t = 0; t < kMaxPts; t++) {
+            acc[t] = wide_zero<F>();
+            if (t < npts)
+                for (size_t i = tid; i < a.count; i += nred) wide_add_fe<F>(acc[t], fe_load<F>(a.partials, (size_t)t * a.count + i));
+        }
+        wave_reduce_wide<F, kMaxPts>(acc, npts);
+        if (lane == 63) {
 #pragma unroll
-        for (int t = 0; t < kMaxPts; t++) sh[t * 16 + wave] = acc[t];
+            for (int t = 0; t < kMaxPts; t++) sh[t * 16 + wave] = acc[t];
+        }
     }
     if (tid < 25) S.st[tid] = a.ctx.sponge->a[tid];
     __syncthreads();
@@ -259,7 +291,7 @@ __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArg
     }
     TS(1);
     uint32_t fill = a.ctx.sponge->fill;
-    round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_slot, a.chal_slot, fill, lane);
+    round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_slot, a.chal_slot, fill, lane, a.flags);
     if (lane < 25) a.ctx.sponge->a[lane] = S.st[lane];
     if (lane == 0) a.ctx.sponge->fill = fill;
     TS(4);
@@ -302,13 +334,17 @@ struct LimbsFinishArgs {
     const uint64_t *limbs;   // element-wise sums over the ranks of partials_to_limbs_kernel's output
     RoundCtx ctx;
     int with_claim;
+    int flags;               // kDerive1: launched with 128 lanes, the second wave evaluates the previous round's message
     size_t claim_slot, msg_slot, chal_slot;
+    size_t prev_msg_slot, prev_chal_slot;
 };
-template <class F> __global__ void __launch_bounds__(64) limbs_finish_kernel(LimbsFinishArgs a) {
+template <class F> __global__ void __launch_bounds__(128) limbs_finish_kernel(LimbsFinishArgs a) {
     __shared__ RoundShared<F> S;
-    const unsigned lane = threadIdx.x;
-    if (lane < 25) S.st[lane] = a.ctx.sponge->a[lane];
-    if ((int)lane < a.ctx.npts) {
+    const unsigned lane = threadIdx.x & 63u;
+    if (threadIdx.x >= 64) {
+        if (lane == 0) S.claim = previous_claim<F>(a.ctx, a.prev_msg_slot, a.prev_chal_slot);
+    } else if (lane < 25) S.st[lane] = a.ctx.sponge->a[lane];
+    if (threadIdx.x < 64 && (int)lane < a.ctx.npts) {
         Wide<F> w;
         uint64_t c = 0;
 #pragma unroll
@@ -319,9 +355,10 @@ template <class F> __global__ void __launch_bounds__(64) limbs_finish_kernel(Lim
         }
         S.ev[lane] = wide_reduce<F>(w);
     }
-    wave_lds_sync();
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
     uint32_t fill = a.ctx.sponge->fill;
-    round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_slot, a.chal_slot, fill, lane);
+    round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_slot, a.chal_slot, fill, lane, a.flags);
     if (lane < 25) a.ctx.sponge->a[lane] = S.st[lane];
     if (lane == 0) a.ctx.sponge->fill = fill;
 }

@@ -27,7 +27,7 @@ struct SumPolyTables {
 
 // accumulate the NFAC+1 evaluation terms of one product at one pair index
 template <class F, int NFAC>
-__device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const Fe<F> (&hi)[NFAC], Wide<F> (&acc)[NFAC + 1]) {
+__device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const Fe<F> (&hi)[NFAC], Wide<F> (&acc)[NFAC + 1], int skip1 = 0) {
     Fe<F> v[NFAC], d[NFAC];
 #pragma unroll
     for (int f = 0; f < NFAC; f++) {
@@ -36,10 +36,12 @@ __device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const 
     }
 #pragma unroll
     for (int t = 0; t <= NFAC; t++) {
-        Fe<F> term = v[0];
+        if (!(skip1 && t == 1)) {                            // the point 1 is derived from the running claim (dev_transcript.cuh)
+            Fe<F> term = v[0];
 #pragma unroll
-        for (int f = 1; f < NFAC; f++) term = fe_mul<F>(term, v[f]);
-        wide_add_fe<F>(acc[t], term);
+            for (int f = 1; f < NFAC; f++) term = fe_mul<F>(term, v[f]);
+            wide_add_fe<F>(acc[t], term);
+        }
         if (t < NFAC) {
 #pragma unroll
             for (int f = 0; f < NFAC; f++) v[f] = fe_add<F>(v[f], d[f]);   // X_{t+1} = X_t + (hi - lo)
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
 // as the (lo, hi) pair of the NEXT round.
 template <class F, int NFAC>
 __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials,
-                                                                  const void *__restrict__ rp = nullptr) {
+                                                                  const void *__restrict__ rp = nullptr, int skip1 = 0) {
     __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];
     Wide<F> acc[NFAC + 1];
 #pragma unroll
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables 
                 fe_store<F>(dst, i, lo[f]);
                 fe_store<F>(dst, i + q, hi[f]);
             }
-            accumulate_terms<F, NFAC>(lo, hi, acc);
+            accumulate_terms<F, NFAC>(lo, hi, acc, skip1);
         }
     }
     write_partials<F, NFAC>(acc, sh, partials);

@@ -114,13 +114,18 @@ template <class F> struct DeviceRounds {
         return ZK_OK;
     }
     RoundCtx ctx(int npts, int mode) const { return RoundCtx{npts, mode, sponge(), basis(), proof()}; }
+    // derive_prev = 1: the producer skipped the point 1; it is derived from the previous round's message, whose slots precede
+    // this round's by `per` (dev_transcript.cuh kDerive1)
     int launch_finish(const void *partials, size_t count, int npts, int mode, int with_claim, size_t claim_slot, size_t msg_slot,
-                      size_t chal_slot) {
+                      size_t chal_slot, int derive_prev = 0, size_t per = 0) {
         FinishArgs a{};
-        a.partials = partials; a.count = count; a.ctx = ctx(npts, mode); a.with_claim = with_claim;
+        a.partials = partials; a.count = count; a.ctx = ctx(npts, mode); a.with_claim = with_claim; a.flags = derive_prev ? kDerive1 : 0;
         a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
+        a.prev_msg_slot = msg_slot - per; a.prev_chal_slot = chal_slot - per;
         size_t threads = (count + 63) / 64 * 64;          // one partial per lane up to 1024 lanes
-        if (threads > (size_t)kFinishBlock) threads = kFinishBlock;
+        const size_t cap = (size_t)kFinishBlock - (derive_prev ? 64 : 0);
+        if (threads > cap) threads = cap;
+        if (derive_prev) threads += 64;                   // the helper wave
         sumcheck_finish_kernel<F><<<1, (int)threads, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
@@ -268,10 +273,10 @@ template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, 
     return ZK_OK;
 }
 template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t q, const Fe<F> &r, void *part, int grid,
-                                               const void *rp = nullptr) {
-    if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
-    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
-    else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
+                                               const void *rp = nullptr, int skip1 = 0) {
+    if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
+    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
+    else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -356,8 +361,12 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
         size_t ol = cl / 2, q = cl / 4;
         for (size_t k = 0; k < ntab; k++) tabs.out[k] = dst + k * ol * esz;
         int grid = reduce_grid_for(q);                                 // :57 fused with next round's :41
-        ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp)));
-        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, per * (round + 1), per * (round + 1) + npts));
+        // large rounds skip the products of the point 1: e(1) = p_round(r_round) - e(0), derived in the finish step
+        // (dev_transcript.cuh kDerive1).  Below ~2^14 pair indices the helper wave's two products take longer than the
+        // reduction they hide behind, so small rounds evaluate the point 1 directly (measured r1: 4 x 2^22 1.28 -> 1.23 ms).
+        const int skip1 = q >= ((size_t)1 << 14) ? 1 : 0;
+        ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1)));
+        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, per * (round + 1), per * (round + 1) + npts, skip1, per));
         for (size_t k = 0; k < ntab; k++) tabs.in[k] = tabs.out[k];
         char *nx = other;
         other = dst;
@@ -423,6 +432,7 @@ template <class F> struct RoundsImpl : RoundsBase {
     size_t msg_base, chal_base, per, fin_slot;
     size_t round = 0;                                    // rounds absorbed so far
     bool tail_done = false;
+    bool skipped1 = false;                               // the limbs on their way lack the point 1 (derived in absorb)
     DeviceRounds<F> dr;
     DevBuf tailbuf;
 
@@ -456,6 +466,7 @@ template <class F> struct RoundsImpl : RoundsBase {
         void *part;
         ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
         ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
+        skipped1 = false;
         return to_limbs(part, grid, limbs);
     }
     int fold_evals(const zk_table *const *in, zk_table *const *out, uint64_t *limbs) override {
@@ -473,7 +484,9 @@ template <class F> struct RoundsImpl : RoundsBase {
             int grid = reduce_grid_for(q);
             void *part;
             ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
-            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp)));
+            const int skip1 = q >= ((size_t)1 << 14) ? 1 : 0;
+            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1)));
+            skipped1 = skip1 != 0;                                       // e(1) = claim - e(0), after the all-reduce
             ZK_TRY(to_limbs(part, grid, limbs));
         } else {                                                         // 2 entries -> 1: nothing left to evaluate
             for (size_t k = 0; k < ntab; k++) {
@@ -488,8 +501,10 @@ template <class F> struct RoundsImpl : RoundsBase {
         if (!limbs || round >= nrounds) return ZK_E_ARG;
         LimbsFinishArgs a{};
         a.limbs = limbs; a.ctx = dr.ctx((int)npts, mode); a.with_claim = (mode == 0 && round == 0) ? 1 : 0;
+        a.flags = skipped1 ? kDerive1 : 0;
         a.claim_slot = 0; a.msg_slot = msg_base + per * round; a.chal_slot = chal_base + per * round;
-        limbs_finish_kernel<F><<<1, 64, 0, cur_stream()>>>(a);
+        a.prev_msg_slot = a.msg_slot - per; a.prev_chal_slot = a.chal_slot - per;      // used with kDerive1 only (round >= 1)
+        limbs_finish_kernel<F><<<1, skipped1 ? 128 : 64, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
         round++;
         return ZK_OK;
