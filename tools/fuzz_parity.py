@@ -1,0 +1,162 @@
+"""Randomised differential check of the HIP path against the CPU oracle (test infrastructure, like tests/).
+
+    python tools/fuzz_parity.py --seconds 120 --seed 1
+
+Every iteration draws a field, a size, an operation and a value pattern -- uniformly random elements, or tables made of the
+extreme values {0, 1, 2, p-2, p-1}, which maximise the lazily reduced sums of the round kernels -- and compares the result of the
+C-ABI call bit for bit with the oracle's.  Prints one JSON line per operation kind with the number of cases run."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G                     # noqa: E402
+from oracle import oracle as O                  # noqa: E402
+
+FIELDS = [0, 2, 3]                              # BLS12-381 Fr, BN254 Fq, BN254 Fr (the 4-limb fields of the provers)
+
+
+def table(zk, rng, field, n, mode):
+    if mode == "random":
+        t = np.zeros((n, zk.limbs(field)), np.uint64)
+        assert zk.lib().zk_host_fill_random(field, int(rng.integers(1, 1 << 31)), 0, n, t.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+        return t
+    p = O.modulus(field)
+    pool = [0, 1, 2, p - 2, p - 1]
+    if mode == "max":
+        pool = [p - 1]
+    vals = [pool[int(i)] for i in rng.integers(0, len(pool), n)]
+    return zk.from_ints(field, vals)
+
+
+def mk_sum(zk, field, tabs):
+    S = zk.sumcheck
+    return S.SumPolynomial([S.ProductPolynomial([zk.MultilinearPolynomial(field, t) for t in prod]) for prod in tabs])
+
+
+def op_fold(zk, rng, field, mode):
+    logn = int(rng.integers(1, 15))
+    t = table(zk, rng, field, 1 << logn, mode)
+    var = int(rng.integers(0, logn))
+    r = table(zk, rng, field, 1, mode)[0]
+    got = zk.MultilinearPolynomial.partial_evaluate(zk.MultilinearPolynomial(field, t), var, r).evaluated_values
+    assert np.array_equal(got, O.partial_evaluate(field, t, var, r)), ("fold", field, logn, var, mode)
+
+
+def op_evaluate(zk, rng, field, mode):
+    logn = int(rng.integers(0, 15))
+    t = table(zk, rng, field, 1 << logn, mode)
+    k = int(rng.integers(0, logn + 1))
+    pt = table(zk, rng, field, max(k, 1), mode)[:k]
+    got = zk.MultilinearPolynomial(field, t).evaluate(pt)
+    assert np.array_equal(np.asarray(got).reshape(-1), np.asarray(O.evaluate(field, t, pt)).reshape(-1)), ("evaluate", field, logn, k, mode)
+
+
+def op_basic(zk, rng, field, mode, big=False):
+    logn = int(rng.integers(17, 20)) if big else int(rng.integers(0, 16))
+    t = table(zk, rng, field, 1 << logn, mode)
+    prover = zk.Prover.init(field, t)
+    proof = prover.prove()
+    cs, rp, ch = O.sumcheck_basic_prove(field, t)
+    assert np.array_equal(proof.initial_claimed_sum, cs), ("basic claimed", field, logn, mode)
+    assert np.array_equal(proof.round_univariate_polynomials.reshape(rp.shape), rp), ("basic rounds", field, logn, mode)
+    assert np.array_equal(np.asarray(prover.challenges).reshape(ch.shape), ch), ("basic challenges", field, logn, mode)
+    assert zk.Verifier.init().verify(proof) is True
+
+
+def op_gkr_sumcheck(zk, rng, field, mode, big=False):
+    nprod, nfac = int(rng.integers(2, 5)), int(rng.integers(2, 4))
+    logn = int(rng.integers(1, 15 if nprod * nfac <= 4 else 13))
+    if big:                 # the large-round path: evaluation at 1 derived from the running claim, multi-block reductions
+        nprod, nfac, logn = 2, 2, int(rng.integers(16, 19))
+    n = 1 << logn
+    tabs = np.stack([np.stack([table(zk, rng, field, n, mode) for _ in range(nfac)]) for _ in range(nprod)])
+    sp = mk_sum(zk, field, tabs)
+    assert np.array_equal(zk.sumcheck.generate_round_univariate(sp), O.gkr_round_univariate(field, tabs)), ("round", field, nprod, nfac, logn, mode)
+    claimed = O.vec_sum(field, O.sumpoly_reduce(field, tabs))
+    prefix = bytes(rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8))      # any sponge fill
+    t_gpu, t_cpu = zk.Transcript(), O.Transcript()
+    t_gpu.append(prefix)
+    t_cpu.append(prefix)
+    res = zk.sumcheck.prove(sp, claimed, t_gpu)
+    co, ch = O.sumcheck_gkr_prove(field, tabs, claimed, t_cpu)
+    assert np.array_equal(res.round_univariate_polynomials, co), ("gkr coeffs", field, nprod, nfac, logn, mode, len(prefix))
+    assert np.array_equal(res.random_challenges, ch), ("gkr challenges", field, nprod, nfac, logn, mode, len(prefix))
+    assert t_gpu.sample_random_challenge() == t_cpu.sample_random_challenge()
+
+
+def op_msm(zk, rng, field, mode):
+    n = int(rng.integers(1, 700))
+    sc = table(zk, rng, 0, n, mode)
+    a = zk.from_ints(0, [int(rng.integers(1, 1 << 62))])[0]
+    d = zk.from_ints(0, [int(rng.integers(0, 3)) if mode != "random" else int(rng.integers(1, 1 << 62))])[0]   # d = 0: all bases equal
+    bases = zk.G1Bases.synthetic(n, a, d)
+    c = int(rng.choice([0, 2, 4, 7, 11, 13, 16]))
+    got, _ = zk.kzg.msm(zk.MultilinearPolynomial.vector(0, sc), bases, c, True)
+    want = O.kzg_commit(sc, bases.points())
+    assert np.array_equal(np.asarray(got), np.asarray(want)), ("msm", n, c, mode)
+
+
+def op_kzg(zk, rng, field, mode):
+    nv = int(rng.integers(1, 8))
+    taus = table(zk, rng, 0, nv, "random")
+    vals = table(zk, rng, 0, 1 << nv, mode)
+    opening = table(zk, rng, 0, nv, mode)
+    setup = zk.kzg.TrustedSetup.initialize_setup(taus)
+    pts = setup.g1_powers_of_tau.points()
+    assert np.array_equal(pts, O.kzg_setup_g1(taus)), ("setup", nv)
+    kzg = zk.kzg.MultilinearKZG
+    com = kzg.commit_to_polynomial(zk.MultilinearPolynomial(0, vals), setup)
+    assert np.array_equal(np.asarray(com), np.asarray(O.kzg_commit(vals, pts))), ("commit", nv, mode)
+    proof = kzg.open_and_prove(zk.MultilinearPolynomial(0, vals), setup, opening)
+    ev, qs = O.kzg_open(vals, pts, opening)
+    assert np.array_equal(np.asarray(proof.evaluation).reshape(-1), np.asarray(ev).reshape(-1)), ("open value", nv, mode)
+    assert np.array_equal(np.asarray(proof.proofs), np.asarray(qs)), ("open proofs", nv, mode)
+
+
+def op_big_gkr(zk, rng, field, mode):
+    op_gkr_sumcheck(zk, rng, field, mode, True)
+
+
+def op_big_basic(zk, rng, field, mode):
+    op_basic(zk, rng, field, mode, True)
+
+
+OPS = {"big_gkr": op_big_gkr, "big_basic": op_big_basic, "fold": op_fold, "evaluate": op_evaluate, "basic_sumcheck": op_basic, "gkr_sumcheck": op_gkr_sumcheck, "msm": op_msm, "kzg": op_kzg}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--ops", default=",".join(o for o in OPS if not o.startswith("big_")))
+    args = ap.parse_args()
+    zk = G.import_package()
+    from zkmle_amd import _lib
+    _lib.check(zk.lib().zk_init(0))
+    O.lib()
+    rng = np.random.default_rng(args.seed)
+    names = [o for o in args.ops.split(",") if o]
+    counts = {o: 0 for o in names}
+    t0 = time.time()
+    last = t0
+    while time.time() - t0 < args.seconds:
+        name = names[int(rng.integers(0, len(names)))]
+        field = FIELDS[int(rng.integers(0, len(FIELDS)))]
+        mode = ["random", "random", "extreme", "max"][int(rng.integers(0, 4))]
+        OPS[name](zk, rng, field, mode)
+        counts[name] += 1
+        if time.time() - last > 30:
+            last = time.time()
+            print(json.dumps({"elapsed_s": round(last - t0, 1), "cases": counts}), flush=True)
+    print(json.dumps({"seed": args.seed, "seconds": args.seconds, "cases": counts, "mismatches": 0}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
