@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as G                     # noqa: E402
 from oracle import oracle as O                  # noqa: E402
 
+PANICS = {"both_panic": 0, "oracle_panic_sparse_skipped": 0}
 FIELDS = [0, 2, 3]                              # BLS12-381 Fr, BN254 Fq, BN254 Fr (the 4-limb fields of the provers)
 
 
@@ -120,6 +121,83 @@ def op_kzg(zk, rng, field, mode):
     assert np.array_equal(np.asarray(proof.proofs), np.asarray(qs)), ("open proofs", nv, mode)
 
 
+def _random_circuit(rng, depth, dup_ok):
+    """the reference's shape: layer i has 2^i outputs reading 2^(i+1) wires; some outputs are sums of several gates (+=,
+    arithmetic_circuit.rs:96), some have none"""
+    spec = []
+    for i in range(depth):
+        n_out, n_in = 1 << i, 1 << (i + 1)
+        seen, layer = set(), []
+        for o in range(n_out):
+            for _ in range(int(rng.choice([0, 1, 1, 1, 1, 1, 2, 3]))):
+                g = (int(rng.integers(0, n_in)), int(rng.integers(0, n_in)), o, int(rng.integers(0, 2)))
+                if dup_ok or g not in seen:
+                    seen.add(g)
+                    layer.append(g)
+        if not layer:
+            layer.append((0, min(1, n_in - 1), 0, 0))
+        spec.append(layer)
+    return spec
+
+
+def _ints(zk, rng, field, n, mode):
+    return table(zk, rng, field, n, mode)
+
+
+def op_gkr_dense(zk, rng, field, mode):
+    depth = int(rng.integers(1, 6))
+    spec = _random_circuit(rng, depth, False)
+    x = _ints(zk, rng, field, 1 << depth, mode)
+    circuit = zk.Circuit.new(field, [zk.Layer.new([zk.Gate.new(*g) for g in layer]) for layer in spec])
+    try:
+        want = O.gkr_prove(field, spec, x)
+    except O.OraclePanic:                       # e.g. a layer whose evaluation vector is not a power of two
+        try:
+            zk.gkr.prove(circuit, x)
+        except zk.ReferencePanic:
+            PANICS["both_panic"] += 1
+            return
+        raise AssertionError(("gkr dense: oracle panics, library does not", field, depth, spec))
+    proof = zk.gkr.prove(circuit, x)
+    claims, co, ch = proof._flat
+    for got, key in ((proof.circuit_output, "circuit_output"), (proof.claimed_sum, "claimed_sum"), (claims, "layer_claims"), (co, "coeffs"),
+                     (ch, "challenges"), (proof.wb_evaluations, "wb_evals"), (proof.wc_evaluations, "wc_evals")):
+        assert np.array_equal(got, want[key]), ("gkr dense", key, field, depth, mode, spec)
+    assert zk.gkr.verify(circuit, proof, x) is True
+
+
+def op_gkr_sparse(zk, rng, field, mode):
+    depth = int(rng.integers(1, 6))
+    spec = _random_circuit(rng, depth, False)
+    x = _ints(zk, rng, field, 1 << depth, mode)
+    rows = [np.array(layer, np.uint64).reshape(-1, 4) for layer in spec]
+    ob = [1] + list(range(1, depth))
+    try:
+        want = O.gkr_prove(field, spec, x)
+    except O.OraclePanic:                       # the sparse prover pads where the dense reference panics: nothing to compare
+        PANICS["oracle_panic_sparse_skipped"] += 1
+        return
+    proof = zk.gkr.sparse_prove(field, rows, ob, x)
+    out = want["circuit_output"]
+    assert np.array_equal(proof.circuit_output[: len(out)], out) and not proof.circuit_output[len(out):].any(), ("sparse out", field, depth, mode, spec)
+    for got, key in ((proof.claimed_sum, "claimed_sum"), (proof.layer_claims, "layer_claims"), (proof.coeffs, "coeffs"),
+                     (proof.challenges, "challenges"), (proof.wb_evals, "wb_evals"), (proof.wc_evals, "wc_evals")):
+        assert np.array_equal(got, want[key]), ("gkr sparse", key, field, depth, mode, spec)
+    assert zk.gkr.sparse_verify(field, rows, ob, proof, x) is True
+
+
+def op_elementwise(zk, rng, field, mode):
+    MP = zk.MultilinearPolynomial
+    logn = int(rng.integers(0, 8))
+    a, b = table(zk, rng, field, 1 << logn, mode), table(zk, rng, field, 1 << logn, mode)
+    s = table(zk, rng, field, 1, mode)[0]
+    assert np.array_equal(MP(field, a).scalar_mul(s).evaluated_values, O.scalar_mul(field, a, s)), ("scalar_mul", field, logn, mode)
+    assert np.array_equal(MP.add_polynomials(MP(field, a), MP(field, b)).evaluated_values, O.add_polynomials(field, a, b)), ("add", field, logn, mode)
+    assert np.array_equal(MP.polynomial_tensor_add(MP(field, a), MP(field, b)).evaluated_values, O.polynomial_tensor_add(field, a, b))
+    assert np.array_equal(MP.polynomial_tensor_mul(MP(field, a), MP(field, b)).evaluated_values, O.polynomial_tensor_mul(field, a, b))
+    assert MP(field, a).convert_to_bytes() == O.mle_to_bytes(field, a)
+
+
 def op_big_gkr(zk, rng, field, mode):
     op_gkr_sumcheck(zk, rng, field, mode, True)
 
@@ -128,7 +206,8 @@ def op_big_basic(zk, rng, field, mode):
     op_basic(zk, rng, field, mode, True)
 
 
-OPS = {"big_gkr": op_big_gkr, "big_basic": op_big_basic, "fold": op_fold, "evaluate": op_evaluate, "basic_sumcheck": op_basic, "gkr_sumcheck": op_gkr_sumcheck, "msm": op_msm, "kzg": op_kzg}
+OPS = {"big_gkr": op_big_gkr, "big_basic": op_big_basic, "gkr_dense": op_gkr_dense, "gkr_sparse": op_gkr_sparse, "elementwise": op_elementwise,
+       "fold": op_fold, "evaluate": op_evaluate, "basic_sumcheck": op_basic, "gkr_sumcheck": op_gkr_sumcheck, "msm": op_msm, "kzg": op_kzg}
 
 
 def main():
@@ -155,7 +234,7 @@ def main():
         if time.time() - last > 30:
             last = time.time()
             print(json.dumps({"elapsed_s": round(last - t0, 1), "cases": counts}), flush=True)
-    print(json.dumps({"seed": args.seed, "seconds": args.seconds, "cases": counts, "mismatches": 0}), flush=True)
+    print(json.dumps({"seed": args.seed, "seconds": args.seconds, "cases": counts, "panics": PANICS, "mismatches": 0}), flush=True)
 
 
 if __name__ == "__main__":
