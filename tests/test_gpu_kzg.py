@@ -243,3 +243,50 @@ def test_msm_config5_size_2p24(zk):
     ai, di = O.to_ints(O.FR381, np.stack([a, d]))
     k = (ai * s_sum + di * is_sum) % R
     assert O.g1_affine_ints(got) == M.g1_mul(M.G1, k)
+
+
+def test_open_large_levels_on_side_streams_2p21(zk):
+    """2^21 terms: one level MSM (2^20 terms) plus the batched pass of the small levels run on two host threads with their own
+    streams (zk_kzg_open); the pairing check and the projected identity accept the proof, and it equals the one-thread proof"""
+    rng = random.Random(21)
+    nv = 21
+    taus_i = [rng.randrange(R) for _ in range(nv)]
+    taus = zk.from_ints(0, taus_i)
+    setup = zk.TrustedSetup.initialize_setup(taus)
+    poly = zk.MultilinearPolynomial.random(0, 1 << nv, 2121)
+    c = zk.MultilinearKZG.commit_to_polynomial(poly, setup)
+    opening_i = [rng.randrange(R) for _ in range(nv)]
+    opening = zk.from_ints(0, opening_i)
+    proof = zk.MultilinearKZG.open_and_prove(poly, setup, opening)
+    again = zk.MultilinearKZG.open_and_prove(poly, setup, opening)
+    assert np.array_equal(proof.proofs, again.proofs) and np.array_equal(proof.evaluation, again.evaluation)
+    assert zk.MultilinearKZG.verify(setup, c, opening, proof) is True
+    bad = proof.proofs.copy()
+    bad[0] = proof.proofs[1]
+    assert zk.MultilinearKZG.verify(setup, c, opening, zk.MultilinearKZGProof(proof.evaluation, bad)) is False
+
+
+def test_msm_and_open_on_a_nonblocking_user_stream(zk):
+    """every launch of the MSM pipeline follows the thread's current stream (zk_set_stream): a non-blocking stream does not
+    synchronise with the null stream, so a stray null-stream launch would read unsorted indices"""
+    import torch
+    n = 1 << 13
+    scalars = rand_fr(zk, n, 77)
+    a, d = rand_fr(zk, 2, 78)
+    bases = zk.G1Bases.synthetic(n, a, d)
+    want = O.kzg_commit(scalars[:256], bases.points()[:256])
+    st = torch.cuda.Stream()
+    L = zk.lib()
+    L.zk_set_stream.argtypes = [C.c_void_p]
+    assert L.zk_set_stream(C.c_void_p(st.cuda_stream)) == 0
+    try:
+        small = zk.G1Bases(bases.points()[:256])
+        got = zk.kzg.msm(zk.MultilinearPolynomial.vector(0, scalars[:256]), small)
+        assert np.array_equal(got, want)
+        ai, di = O.to_ints(O.FR381, np.stack([a, d]))
+        s_int = O.to_ints(O.FR381, scalars)
+        k = (ai * sum(s_int) + di * sum(i * s for i, s in enumerate(s_int))) % R
+        got = zk.kzg.msm(zk.MultilinearPolynomial.vector(0, scalars), bases)
+        assert O.g1_affine_ints(got) == M.g1_mul(M.G1, k)
+    finally:
+        assert L.zk_set_stream(None) == 0

@@ -5,7 +5,9 @@
 #include <string.h>
 
 #include <memory>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "context.h"
@@ -207,7 +209,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     if (c < 6) ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, cur_stream()));
     if (nseg) {
         ZK_TRY(launch_msm_bucket_sum(d_bases, (const uint32_t *)sorted.p, (const uint64_t *)starts.p, (const uint32_t *)seg_starts.p,
-                                     nbuckets, seg_len, nseg, partials.p, nullptr));
+                                     nbuckets, seg_len, nseg, partials.p, cur_stream()));
     }
     // heavy buckets (skewed scalars, or the short top window): combine partials 16 at a time until every
     // bucket has at most 16, so no lane ever runs a long serial chain of full additions
@@ -544,6 +546,31 @@ int zk_kzg_opening_key_free(zk_kzg_opening_key *k) {
     return ZK_OK;
 }
 
+// Side streams for the level MSMs of an opening (one set per device, created on first use and kept: the scratch pool caches
+// its blocks per stream).
+static std::mutex g_open_mu;
+static std::vector<std::vector<hipStream_t>> g_open_streams;
+static int open_side_streams(int dev, unsigned count, std::vector<hipStream_t> &out) {
+    std::lock_guard<std::mutex> lk(g_open_mu);
+    if ((int)g_open_streams.size() <= dev) g_open_streams.resize(dev + 1);
+    std::vector<hipStream_t> &v = g_open_streams[dev];
+    while (v.size() < count) {
+        hipStream_t st = nullptr;
+        ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        v.push_back(st);
+    }
+    out.assign(v.begin(), v.begin() + count);
+    return ZK_OK;
+}
+static unsigned open_threads() {
+    static const unsigned k = [] { const char *e = getenv("ZK_KZG_OPEN_THREADS"); int v = e ? atoi(e) : 3; return (unsigned)(v < 1 ? 1 : (v > 4 ? 4 : v)); }();
+    return k;
+}
+
+// open_and_prove (multilinear_kzg.rs:50-126).  The quotients of all levels come from one chain of folds on the caller's stream;
+// the level MSMs are independent of each other, so the large ones and the batched pass of the small ones are then handed to
+// `ZK_KZG_OPEN_THREADS` (default 3) host threads, each driving its own stream: the latency-bound phases of one MSM (bucket
+// reduction levels, scans, host read-backs: ~1.4 ms per MSM) run under the bucket phase of another.
 int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg_opening_key *key, const uint64_t *opening,
                 size_t nopen, size_t n_g2, uint64_t *evaluation, uint64_t *proofs) {
     if (!poly || !g1_powers || !opening || !evaluation || !proofs) return ZK_E_ARG;
@@ -560,47 +587,78 @@ int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg
     }
     int rc = ZK_OK;
     if (key->nvars != nopen) rc = ZK_E_KZG_LEN;
-    zk_table *sub = nullptr, *nxt = nullptr, *q = nullptr;
+    zk_table *sub = nullptr, *nxt = nullptr;
     if (rc == ZK_OK) rc = zk_mle_evaluate(poly, opening, nopen, evaluation);                    // :70
     if (rc == ZK_OK) rc = zk_table_alloc(ZK_FR381, poly->len, &sub);
     if (rc == ZK_OK) rc = zk_mle_sub_scalar(poly, evaluation, sub, nullptr);                    // :74-80
     if (rc == ZK_OK && poly->len >= 2) rc = zk_table_alloc(ZK_FR381, poly->len / 2, &nxt);
-    if (rc == ZK_OK && poly->len >= 2) rc = zk_table_alloc(ZK_FR381, poly->len / 2, &q);
-    // quotients of the batched (small) levels are collected, zero-padded, in one scalar buffer [j][2^small_bits]
+    // quotients of the batched (small) levels are collected, zero-padded, in one scalar buffer [j][2^small_bits];
+    // those of the large levels lie end to end in `bigq` (level i at offset len - len / 2^i)
     const bool batched = key->small_u != nullptr && rc == ZK_OK;
     const size_t nlev = key->small_bits + 1, small_total = ((size_t)1 << nlev) - 1;
-    DevBuf smallq;
+    const size_t nbig = batched ? key->small_t0 - 1 : nopen;          // levels t = 1 .. nbig take a plain MSM each
+    DevBuf smallq, bigq;
     if (batched) rc = smallq.alloc(small_total * 32);
+    if (rc == ZK_OK && nbig) rc = bigq.alloc(poly->len * 32);
+    std::vector<size_t> big_off(nbig + 1, 0);
     for (size_t i = 0; i < nopen && rc == ZK_OK; i++) {                                          // :86
         size_t half = sub->len / 2;
         const size_t t = i + 1;
-        const bool small = batched && t >= key->small_t0;
+        const bool small = t > nbig;
         // batched level j = t - small_t0 sits at offset 2^nlev - 2^(nlev - j) of the end-to-end scalar buffer
-        void *qdst = small ? (void *)((char *)smallq.p + (((size_t)1 << nlev) - ((size_t)1 << (nlev - (t - key->small_t0)))) * 32) : q->dptr;
+        void *qdst = small ? (void *)((char *)smallq.p + (((size_t)1 << nlev) - ((size_t)1 << (nlev - (t - key->small_t0)))) * 32)
+                           : (void *)((char *)bigq.p + big_off[i] * 32);
+        if (!small) big_off[i + 1] = big_off[i] + half;
         // quotient = hi half - lo half (compute_quotient_polynomial :165-179)
         elementwise_kernel<Fr381, OP_HI_MINUS_LO><<<grid_for(half), kBlock, 0, cur_stream()>>>(sub->dptr, nullptr, qdst, half, fe_zero<Fr381>());
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; break; }
-        if (!small) {
-            q->len = half;
-            // proof_i = sum_j [blown_up(q)[j]] B_j  (:96-107)  ==  sum_k [q[k]] B^(i+1)_k
-            G1Xyzz pi;
-            rc = msm_device(q->dptr, key->level[t], half, 0, &pi, nullptr);
-            if (rc != ZK_OK) break;
-            affine_to_u64(g1_to_affine(pi), proofs + 12 * i);
-        }
         nxt->len = half;
         rc = zk_mle_fold(sub, 0, opening + 4 * i, nxt, nullptr);                                 // :113-119
         zk_table *tt = sub; sub = nxt; nxt = tt;
     }
-    if (batched && rc == ZK_OK) {                           // the small levels' proofs: one batched pass
+    if (rc == ZK_OK && hipStreamSynchronize(cur_stream()) != hipSuccess) rc = ZK_E_HIP;
+    // proof_i = sum_j [blown_up(q)[j]] B_j  (:96-107)  ==  sum_k [q[k]] B^(i+1)_k : task i < nbig; task nbig = the batched small levels
+    const size_t ntasks = nbig + (batched ? 1 : 0);
+    auto run_task = [&](size_t k) -> int {
+        if (k < nbig) {
+            G1Xyzz pi;
+            ZK_TRY(msm_device((const char *)bigq.p + big_off[k] * 32, key->level[k + 1], big_off[k + 1] - big_off[k], 0, &pi, nullptr));
+            affine_to_u64(g1_to_affine(pi), proofs + 12 * k);
+            return ZK_OK;
+        }
         std::vector<G1Xyzz> pis(nlev);
-        rc = msm_core(smallq.p, key->small_u, (size_t)1 << key->small_bits, (unsigned)nlev, true, key->small_c, pis.data(), nullptr);
-        for (size_t j = 0; j < nlev && rc == ZK_OK; j++) affine_to_u64(g1_to_affine(pis[j]), proofs + 12 * (key->small_t0 + j - 1));
+        ZK_TRY(msm_core(smallq.p, key->small_u, (size_t)1 << key->small_bits, (unsigned)nlev, true, key->small_c, pis.data(), nullptr));
+        for (size_t j = 0; j < nlev; j++) affine_to_u64(g1_to_affine(pis[j]), proofs + 12 * (key->small_t0 + j - 1));
+        return ZK_OK;
+    };
+    const unsigned nthreads = (unsigned)(ntasks < open_threads() ? ntasks : open_threads());
+    if (rc == ZK_OK && nthreads <= 1) {
+        for (size_t k = 0; k < ntasks && rc == ZK_OK; k++) rc = run_task(k);
+    } else if (rc == ZK_OK) {
+        int dev = 0;
+        std::vector<hipStream_t> streams;
+        if (hipGetDevice(&dev) != hipSuccess) rc = ZK_E_HIP;
+        if (rc == ZK_OK) rc = open_side_streams(dev, nthreads, streams);
+        std::atomic<size_t> next{0};
+        std::vector<int> rcs(nthreads, ZK_OK);
+        std::vector<std::string> errs(nthreads);
+        std::vector<std::thread> workers;
+        for (unsigned w = 0; w < nthreads && rc == ZK_OK; w++)
+            workers.emplace_back([&, w] {
+                if (hipSetDevice(dev) != hipSuccess) { rcs[w] = ZK_E_HIP; return; }
+                zk_set_stream((void *)streams[w]);
+                for (size_t k; (k = next.fetch_add(1)) < ntasks;) {           // largest MSM first (tasks are in level order)
+                    int r = run_task(k);
+                    if (r != ZK_OK) { rcs[w] = r; errs[w] = zk_last_error(); break; }
+                }
+            });
+        for (std::thread &th : workers) th.join();
+        for (unsigned w = 0; w < nthreads && rc == ZK_OK; w++)
+            if (rcs[w] != ZK_OK) { rc = rcs[w]; set_last_error(errs[w]); }
     }
     zk_table_free(sub);
     zk_table_free(nxt);
-    zk_table_free(q);
     zk_kzg_opening_key_free(own);
     return rc;
 }
