@@ -280,7 +280,10 @@ int zk_kzg_commit(const zk_table *poly, const zk_g1_bases *g1_powers, uint64_t *
 /* open_and_prove :50-126.  The reference runs a full-size naive dot product per round over the
  * blown-up quotient; the same group elements are obtained here as MSMs of sizes 2^(n-1) .. 1
  * against pre-summed bases (zk_kzg_opening_key, built once per setup).  n_g2 = the setup's
- * g2_powers_of_tau length (only compared, :60-64).  proofs: nopen affine points. */
+ * g2_powers_of_tau length (only compared, :60-64).  proofs: nopen affine points.
+ * The independent level MSMs of one call run on up to 3 library-owned host threads, each with its
+ * own stream (environment ZK_KZG_OPEN_THREADS = 1 .. 4; 1 keeps everything on the caller's thread
+ * and stream); the call returns when all of them have finished. */
 typedef struct zk_kzg_opening_key zk_kzg_opening_key;
 int zk_kzg_opening_key_new(const zk_g1_bases *g1_powers, zk_kzg_opening_key **out);
 int zk_kzg_opening_key_free(zk_kzg_opening_key *k);
