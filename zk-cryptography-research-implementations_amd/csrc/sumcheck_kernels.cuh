@@ -49,6 +49,160 @@ __device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const 
     }
 }
 
+// ---- products summed BEFORE their Montgomery reduction (degree-2 rounds of the 4-limb fields) --------------------------------------
+// A round evaluation is a sum of products; sum_i mont(a_i, b_i) = mont-reduce(sum_i a_i b_i), so the lane accumulates the raw
+// double-width products (L^2 multiply-adds each instead of 2 L^2, no conversion back to 32-bit limbs) and the workgroup reduces the
+// total once.  The accumulator keeps 2 L + 1 limbs of 29 bits in 32-bit words; every product adds less than 2^29 to a limb, so the
+// carries are propagated every 6 products.  Operands may be any representative below 2^(29 L - 3): the points 0, 1, 2 use lo, hi
+// and 2 hi - lo + 4 p without a modular reduction.
+template <class F> struct ProdConsts;            // c1 = 2^(29 L + SH) mod p, c2 = 2^(58 L + SH) mod p, 29-bit limbs
+template <> struct ProdConsts<Fr381> {
+    static ZK_HD uint32_t c1(int i) { constexpr uint32_t t[9] = {0x1ffff72bu, 0x000046a7u, 0x1f5f3540u, 0x0ce3021cu, 0x118f3661u, 0x008176cbu, 0x054e487cu, 0x102e8190u, 0x001e092eu}; return t[i]; }
+    static ZK_HD uint32_t c2(int i) { constexpr uint32_t t[9] = {0x0e3677f5u, 0x06441022u, 0x10fe35fdu, 0x1f3f5076u, 0x122ddf09u, 0x18425209u, 0x1cd6203au, 0x19a93b3bu, 0x00047c05u}; return t[i]; }
+};
+template <> struct ProdConsts<Bn254Fq> {
+    static ZK_HD uint32_t c1(int i) { constexpr uint32_t t[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u}; return t[i]; }
+    static ZK_HD uint32_t c2(int i) { constexpr uint32_t t[9] = {0x1e46cb83u, 0x072a411eu, 0x0feb9db7u, 0x08e6e8f9u, 0x0746d786u, 0x0ae2ff90u, 0x01e5e885u, 0x0d1ba21au, 0x0027a08bu}; return t[i]; }
+};
+template <> struct ProdConsts<Bn254Fr> {
+    static ZK_HD uint32_t c1(int i) { constexpr uint32_t t[9] = {0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u}; return t[i]; }
+    static ZK_HD uint32_t c2(int i) { constexpr uint32_t t[9] = {0x16d37a7au, 0x08833f88u, 0x0b72dfe0u, 0x07e2bbadu, 0x097730eau, 0x0de737eau, 0x1ed2d8f6u, 0x03e94703u, 0x001e4f71u}; return t[i]; }
+};
+template <class F> struct LazyProducts { static constexpr bool value = false; };
+template <> struct LazyProducts<Fr381> { static constexpr bool value = true; };
+template <> struct LazyProducts<Bn254Fq> { static constexpr bool value = true; };
+template <> struct LazyProducts<Bn254Fr> { static constexpr bool value = true; };
+
+template <class F> struct ProdAcc {
+    uint32_t l[2 * UParams<F>::L + 1];
+};
+constexpr int kProdCarryEvery = 6;
+template <class F> __device__ __forceinline__ ProdAcc<F> prod_zero() {
+    ProdAcc<F> a;
+#pragma unroll
+    for (int j = 0; j <= 2 * UParams<F>::L; j++) a.l[j] = 0;
+    return a;
+}
+// acc += a * b (integers; limbs of a and b below 2^29)
+template <class F> __device__ __forceinline__ void prod_accumulate(ProdAcc<F> &acc, const Ufe<F> &a, const Ufe<F> &b) {
+    constexpr int L = UParams<F>::L;
+    uint64_t T[2 * L - 1];
+#pragma unroll
+    for (int j = 0; j < 2 * L - 1; j++) T[j] = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+#pragma unroll
+        for (int j = 0; j < L; j++) T[i + j] += (uint64_t)a.l[j] * b.l[i];
+    }
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 2 * L - 1; j++) {
+        uint64_t v = T[j] + c;
+        acc.l[j] += (uint32_t)v & UMASK;
+        c = v >> UB;
+    }
+    acc.l[2 * L - 1] += (uint32_t)c & UMASK;
+    acc.l[2 * L] += (uint32_t)(c >> UB);
+}
+template <class F> __device__ __forceinline__ void prod_carry(ProdAcc<F> &acc) {
+#pragma unroll
+    for (int j = 0; j < 2 * UParams<F>::L; j++) {
+        acc.l[j + 1] += acc.l[j] >> UB;
+        acc.l[j] &= UMASK;
+    }
+}
+// the three (or two) evaluation terms of one product of two factors at one pair index
+template <class F>
+__device__ __forceinline__ void accumulate_terms_lazy(const Fe<F> (&lo)[2], const Fe<F> (&hi)[2], ProdAcc<F> (&acc)[3], int skip1) {
+    const Ufe<F> l0 = u_from_limbs32<F>(lo[0]), l1 = u_from_limbs32<F>(lo[1]);
+    const Ufe<F> h0 = u_from_limbs32<F>(hi[0]), h1 = u_from_limbs32<F>(hi[1]);
+    prod_accumulate<F>(acc[0], l0, l1);
+    if (!skip1) prod_accumulate<F>(acc[1], h0, h1);
+    prod_accumulate<F>(acc[2], uadd<F>(h0, usub<F>(h0, l0)), uadd<F>(h1, usub<F>(h1, l1)));    // X(2) = 2 hi - lo (+ 4 p)
+}
+// 2 L + 1 normalized 29-bit limbs -> 2 N + 2 saturated 32-bit words
+template <class F> struct ProdWide {
+    uint32_t l[2 * F::N + 2];
+};
+template <class F> __device__ __forceinline__ ProdWide<F> prod_to_wide(const ProdAcc<F> &a) {
+    constexpr int NL = 2 * UParams<F>::L + 1, NW = 2 * F::N + 2;
+    ProdWide<F> r;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const int q = 32 * w, i = q / UB, off = q - UB * i;
+        uint64_t v = i < NL ? (uint64_t)a.l[i] >> off : 0;
+        const int have = UB - off;
+        if (i + 1 < NL) v |= (uint64_t)a.l[i + 1] << have;
+        if (have + UB < 32 && i + 2 < NL) v |= (uint64_t)a.l[i + 2] << (have + UB);
+        r.l[w] = (uint32_t)v;
+    }
+    return r;
+}
+template <class F> __device__ __forceinline__ void prodwide_add(ProdWide<F> &w, const ProdWide<F> &o) {
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < 2 * F::N + 2; i++) w.l[i] = __builtin_addc(w.l[i], o.l[i], c, &c);
+}
+template <class F, int CTRL, int ROW_MASK> __device__ __forceinline__ void prodwide_dpp_step(ProdWide<F> &v) {
+    ProdWide<F> o;
+#pragma unroll
+    for (int k = 0; k < 2 * F::N + 2; k++) o.l[k] = dpp_or_zero<CTRL, ROW_MASK>(v.l[k]);
+    prodwide_add<F>(v, o);
+}
+// S 2^(-32 N) mod p for a sum S of raw products (2 N + 2 words): S = A + B 2^(29 L) + C 2^(58 L), each part times its constant
+template <class F> __device__ __forceinline__ Fe<F> prodwide_reduce(const ProdWide<F> &w) {
+    constexpr int L = UParams<F>::L, NW = 2 * F::N + 2;
+    Ufe<F> part[3], cst[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const int q = UB * (t * L + j), wi = q >> 5, off = q & 31;
+            uint32_t lo_w = wi < NW ? w.l[wi] : 0u, hi_w = (wi + 1) < NW ? w.l[wi + 1] : 0u;
+            uint32_t v = off ? ((lo_w >> off) | (hi_w << (32 - off))) : lo_w;
+            part[t].l[j] = v & UMASK;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        cst[0].l[j] = j == 0 ? (1u << UParams<F>::SH) : 0u;
+        cst[1].l[j] = ProdConsts<F>::c1(j);
+        cst[2].l[j] = ProdConsts<F>::c2(j);
+    }
+    Ufe<F> sum = uadd<F>(uadd<F>(umul<F>(part[0], cst[0]), umul<F>(part[1], cst[1])), umul<F>(part[2], cst[2]));   // < 6 p
+    Ufe<F> ru;
+#pragma unroll
+    for (int j = 0; j < L; j++) ru.l[j] = UParams<F>::r_u(j);
+    return u_to_limbs32<F>(u_reduce_once<F>(umul<F>(sum, ru)));           // x 2^(29 L) / 2^(29 L): the same value, below 2 p
+}
+// workgroup totals of the lazily accumulated products -> partials, same layout as write_partials
+template <class F>
+__device__ __forceinline__ void write_partials_lazy(ProdAcc<F> (&acc)[3], ProdWide<F> *sh, void *partials, int skip1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (k == 1 && skip1) continue;
+        prod_carry<F>(acc[k]);
+        ProdWide<F> v = prod_to_wide<F>(acc[k]);
+        prodwide_dpp_step<F, 0x111, 0xf>(v);
+        prodwide_dpp_step<F, 0x112, 0xf>(v);
+        prodwide_dpp_step<F, 0x114, 0xf>(v);
+        prodwide_dpp_step<F, 0x118, 0xf>(v);
+        prodwide_dpp_step<F, 0x142, 0xa>(v);
+        prodwide_dpp_step<F, 0x143, 0xc>(v);
+        if (lane == 63) sh[k * nw + wave] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= 3) return;
+    Fe<F> tot = fe_zero<F>();
+    if (!(threadIdx.x == 1 && skip1)) {
+        ProdWide<F> t = sh[threadIdx.x * nw];
+        for (int w = 1; w < nw; w++) prodwide_add<F>(t, sh[threadIdx.x * nw + w]);
+        tot = prodwide_reduce<F>(t);
+    }
+    fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
+}
+
 template <class F, int NFAC>
 __device__ __forceinline__ void write_partials(Wide<F> (&acc)[NFAC + 1], Wide<F> *sh, void *partials) {
     Fe<F> tot;
@@ -58,6 +212,30 @@ __device__ __forceinline__ void write_partials(Wide<F> (&acc)[NFAC + 1], Wide<F>
 // tables of `2 * half` entries; partials[t * gridDim.x + block]
 template <class F, int NFAC>
 __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials) {
+    if constexpr (NFAC == 2 && LazyProducts<F>::value) {
+        __shared__ ProdWide<F> shp[3 * kBlock / 64];
+        ProdAcc<F> pacc[3] = {prod_zero<F>(), prod_zero<F>(), prod_zero<F>()};
+        int pending = 0;
+        const size_t pstride = (size_t)gridDim.x * blockDim.x;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += pstride) {
+            for (int p = 0; p < nprod; p++) {
+                Fe<F> lo[2], hi[2];
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    lo[f] = fe_load<F>(tabs.in[p * 2 + f], i);
+                    hi[f] = fe_load<F>(tabs.in[p * 2 + f], i + half);
+                }
+                accumulate_terms_lazy<F>(lo, hi, pacc, 0);
+                if (++pending == kProdCarryEvery) {
+                    pending = 0;
+#pragma unroll
+                    for (int t = 0; t < 3; t++) prod_carry<F>(pacc[t]);
+                }
+            }
+        }
+        write_partials_lazy<F>(pacc, shp, partials, 0);
+        return;
+    }
     __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];
     Wide<F> acc[NFAC + 1];
 #pragma unroll
@@ -82,6 +260,37 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
 template <class F, int NFAC>
 __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials,
                                                                   const void *__restrict__ rp = nullptr, int skip1 = 0) {
+    if constexpr (NFAC == 2 && LazyProducts<F>::value) {
+        __shared__ ProdWide<F> shp[3 * kBlock / 64];
+        ProdAcc<F> pacc[3] = {prod_zero<F>(), prod_zero<F>(), prod_zero<F>()};
+        int pending = 0;
+        const size_t pstride = (size_t)gridDim.x * blockDim.x;
+        const Multiplier<F> pmr(challenge_arg<F>(r, rp));
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += pstride) {
+            for (int p = 0; p < nprod; p++) {
+                Fe<F> lo[2], hi[2];
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    const void *src = tabs.in[p * 2 + f];
+                    void *dst = tabs.out[p * 2 + f];
+                    Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
+                    Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
+                    lo[f] = fe_add<F>(a0, pmr.times(fe_sub<F>(b0, a0)));
+                    hi[f] = fe_add<F>(a1, pmr.times(fe_sub<F>(b1, a1)));
+                    fe_store<F>(dst, i, lo[f]);
+                    fe_store<F>(dst, i + q, hi[f]);
+                }
+                accumulate_terms_lazy<F>(lo, hi, pacc, skip1);
+                if (++pending == kProdCarryEvery) {
+                    pending = 0;
+#pragma unroll
+                    for (int t = 0; t < 3; t++) prod_carry<F>(pacc[t]);
+                }
+            }
+        }
+        write_partials_lazy<F>(pacc, shp, partials, skip1);
+        return;
+    }
     __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];
     Wide<F> acc[NFAC + 1];
 #pragma unroll
