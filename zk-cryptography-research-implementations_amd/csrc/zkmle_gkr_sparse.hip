@@ -52,42 +52,46 @@ struct GateArrays {
     const uint32_t *out, *left, *right, *op;      // SoA on the device
 };
 // w[g] = alpha eqA[out_g] + beta eqB[out_g]   (eqB may be null: layer 0)
-template <class F> __global__ void gate_weights_kernel(GateArrays g, size_t n, const void *eqA, const void *eqB, Fe<F> alpha, Fe<F> beta,
-                                                       void *__restrict__ w) {
+// (`out` is the output index of gate i in whatever order the caller wants the weights: gate order, or one of the grouped orders)
+template <class F> __global__ void gate_weights_kernel(const uint32_t *__restrict__ out, size_t n, const void *eqA, const void *eqB, Fe<F> alpha,
+                                                       Fe<F> beta, void *__restrict__ w) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fe<F> v = fe_load<F>(eqA, g.out[i]);
-    if (eqB) v = fe_add<F>(fe_mul<F>(alpha, v), fe_mul<F>(beta, fe_load<F>(eqB, g.out[i])));
+    Fe<F> v = fe_load<F>(eqA, out[i]);
+    if (eqB) v = fe_add<F>(fe_mul<F>(alpha, v), fe_mul<F>(beta, fe_load<F>(eqB, out[i])));
     fe_store<F>(w, i, v);
 }
-// one lane per left index b (gates grouped by left index: order / start)
-template <class F> __global__ void phase1_tables_kernel(GateArrays g, const uint32_t *__restrict__ order, const uint32_t *__restrict__ start,
-                                                        size_t nb, const void *__restrict__ w, const void *__restrict__ W,
-                                                        void *__restrict__ H1, void *__restrict__ H0) {
+// one lane per left index b.  The gates' right indices and operations are stored once more grouped by left index (start[b] ..
+// start[b + 1]) and read sequentially; the weight (gate order) and W[right] are the two gathers left.  (r1: with every field read
+// through the group's index list the kernel made four gathers per gate, 352 us for 2^22 gates; computing the weights directly in
+// the grouped orders was no better: it turns the sequential eq reads of an output-sorted gate list into two more gathers.)
+template <class F> __global__ void phase1_tables_kernel(const uint32_t *__restrict__ start, size_t nb, const void *__restrict__ w,
+                                                        const uint32_t *__restrict__ order, const uint32_t *__restrict__ right_l,
+                                                        const uint32_t *__restrict__ op_l,
+                                                        const void *__restrict__ W, void *__restrict__ H1, void *__restrict__ H0) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     Fe<F> h1 = fe_zero<F>(), h0 = fe_zero<F>();
     for (uint32_t e = start[b]; e < start[b + 1]; e++) {
-        uint32_t i = order[e];
-        Fe<F> wg = fe_load<F>(w, i);
-        Fe<F> t = fe_mul<F>(wg, fe_load<F>(W, g.right[i]));
-        if (g.op[i] == 0) { h1 = fe_add<F>(h1, wg); h0 = fe_add<F>(h0, t); }     // add gate
+        Fe<F> wg = fe_load<F>(w, order[e]);
+        Fe<F> t = fe_mul<F>(wg, fe_load<F>(W, right_l[e]));
+        if (op_l[e] == 0) { h1 = fe_add<F>(h1, wg); h0 = fe_add<F>(h0, t); }     // add gate
         else h1 = fe_add<F>(h1, t);                                               // mul gate
     }
     fe_store<F>(H1, b, h1);
     fe_store<F>(H0, b, h0);
 }
 // one lane per right index c (gates grouped by right index)
-template <class F> __global__ void phase2_tables_kernel(GateArrays g, const uint32_t *__restrict__ order, const uint32_t *__restrict__ start,
-                                                        size_t nc, const void *__restrict__ w, const void *__restrict__ eqL,
-                                                        void *__restrict__ A, void *__restrict__ M) {
+template <class F> __global__ void phase2_tables_kernel(const uint32_t *__restrict__ start, size_t nc, const void *__restrict__ w,
+                                                        const uint32_t *__restrict__ order, const uint32_t *__restrict__ left_r,
+                                                        const uint32_t *__restrict__ op_r,
+                                                        const void *__restrict__ eqL, void *__restrict__ A, void *__restrict__ M) {
     size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nc) return;
     Fe<F> a = fe_zero<F>(), m = fe_zero<F>();
     for (uint32_t e = start[c]; e < start[c + 1]; e++) {
-        uint32_t i = order[e];
-        Fe<F> t = fe_mul<F>(fe_load<F>(w, i), fe_load<F>(eqL, g.left[i]));
-        if (g.op[i] == 0) a = fe_add<F>(a, t); else m = fe_add<F>(m, t);
+        Fe<F> t = fe_mul<F>(fe_load<F>(w, order[e]), fe_load<F>(eqL, left_r[e]));
+        if (op_r[e] == 0) a = fe_add<F>(a, t); else m = fe_add<F>(m, t);
     }
     fe_store<F>(A, c, a);
     fe_store<F>(M, c, m);
@@ -131,6 +135,7 @@ struct LayerDev {
     uint32_t out_bits = 0, in_bits = 0;
     DevBuf out, left, right, op;                       // u32[ngates]
     DevBuf ord_left, st_left, ord_right, st_right, ord_out, st_out;
+    DevBuf l_right, l_op, r_left, r_op;                // right / op grouped by left index, left / op grouped by right index
     GateArrays arrays() const { return GateArrays{(const uint32_t *)out.p, (const uint32_t *)left.p, (const uint32_t *)right.p, (const uint32_t *)op.p}; }
 };
 // counting sort of gate ids by key: order[], start[nbins + 1]
@@ -247,6 +252,13 @@ __global__ void key_scatter_kernel(const uint32_t *__restrict__ key, size_t n, c
     order[start[k] + atomicAdd(&cursor[k], 1u)] = (uint32_t)i;
 }
 inline unsigned blocks(size_t n);
+__global__ void permute2_kernel(const uint32_t *__restrict__ order, size_t n, const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                uint32_t *__restrict__ oa, uint32_t *__restrict__ ob) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    uint32_t i = order[e];
+    oa[e] = a[i]; ob[e] = b[i];
+}
 int group_by_device(const uint32_t *d_key, size_t n, size_t nbins, DevBuf &order, DevBuf &start) {
     DevBuf cursor;
     ZK_TRY(order.alloc((n ? n : 1) * 4));
@@ -280,6 +292,15 @@ int upload_layer(const zk_gate *g, size_t n, uint32_t out_bits, uint32_t in_bits
     ZK_TRY(group_by_device((const uint32_t *)L.left.p, n, (size_t)1 << in_bits, L.ord_left, L.st_left));
     ZK_TRY(group_by_device((const uint32_t *)L.right.p, n, (size_t)1 << in_bits, L.ord_right, L.st_right));
     ZK_TRY(group_by_device((const uint32_t *)L.out.p, n, (size_t)1 << out_bits, L.ord_out, L.st_out));
+    for (DevBuf *d : {&L.l_right, &L.l_op, &L.r_left, &L.r_op}) ZK_TRY(d->alloc((n ? n : 1) * 4));
+    if (n) {
+        permute2_kernel<<<blocks(n), kBlock, 0, cur_stream()>>>((const uint32_t *)L.ord_left.p, n, (const uint32_t *)L.right.p, (const uint32_t *)L.op.p,
+                                                               (uint32_t *)L.l_right.p, (uint32_t *)L.l_op.p);
+        permute2_kernel<<<blocks(n), kBlock, 0, cur_stream()>>>((const uint32_t *)L.ord_right.p, n, (const uint32_t *)L.left.p, (const uint32_t *)L.op.p,
+                                                               (uint32_t *)L.r_left.p, (uint32_t *)L.r_op.p);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(cur_stream()));
+    }
     return ZK_OK;
 }
 
@@ -357,14 +378,14 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         // gate weights
         TablePtr eqA, eqB;
         DevBuf w;
-        ZK_TRY(w.alloc(ng * esz));
+        ZK_TRY(w.alloc((ng ? ng : 1) * esz));
         if (l == 0) {
             ZK_TRY((eq_table<F>(ra.data(), Ly.out_bits, eqA)));
-            gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>(Ly.arrays(), ng, eqA->dptr, nullptr, fe_zero<F>(), fe_zero<F>(), w.p);
+            if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, nullptr, fe_zero<F>(), fe_zero<F>(), w.p);
         } else {
             ZK_TRY((eq_table<F>(rb.data(), Ly.out_bits, eqA)));
             ZK_TRY((eq_table<F>(rc.data(), Ly.out_bits, eqB)));
-            gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>(Ly.arrays(), ng, eqA->dptr, eqB->dptr, load_el<F>(alpha), load_el<F>(beta), w.p);
+            if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, eqB->dptr, load_el<F>(alpha), load_el<F>(beta), w.p);
         }
         ZK_HIP(hipGetLastError());
         // phase 1: W H1 + H0 * 1
@@ -372,8 +393,8 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         ZK_TRY(alloc_table(F::ID, nk, H1));
         ZK_TRY(alloc_table(F::ID, nk, H0));
         ZK_TRY(alloc_table(F::ID, nk, ones));
-        phase1_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(Ly.arrays(), (const uint32_t *)Ly.ord_left.p, (const uint32_t *)Ly.st_left.p, nk, w.p,
-                                                         Wn->dptr, H1->dptr, H0->dptr);
+        phase1_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_left.p, nk, w.p, (const uint32_t *)Ly.ord_left.p,
+                                                         (const uint32_t *)Ly.l_right.p, (const uint32_t *)Ly.l_op.p, Wn->dptr, H1->dptr, H0->dptr);
         fill_one_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(ones->dptr, nk);
         ZK_HIP(hipGetLastError());
         memcpy(layer_claims + l * L64, claim, L64 * 8);
@@ -391,8 +412,8 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         ZK_TRY(alloc_table(F::ID, nk, M));
         ZK_TRY(alloc_table(F::ID, nk, upw));
         ZK_TRY(alloc_table(F::ID, nk, utw));
-        phase2_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(Ly.arrays(), (const uint32_t *)Ly.ord_right.p, (const uint32_t *)Ly.st_right.p, nk, w.p,
-                                                         eqL->dptr, A->dptr, M->dptr);
+        phase2_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_right.p, nk, w.p, (const uint32_t *)Ly.ord_right.p,
+                                                         (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, eqL->dptr, A->dptr, M->dptr);
         uw_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(Wn->dptr, nk, load_el<F>(u), upw->dptr, utw->dptr);
         ZK_HIP(hipGetLastError());
         const zk_table *t2[4] = {A.get(), upw.get(), M.get(), utw.get()};
@@ -438,7 +459,7 @@ template <class F> int wiring_eval(const zk_gate *g, size_t ngates, uint32_t out
     ZK_TRY((eq_table<F>(rc, in_bits, eqR)));
     DevBuf w;
     ZK_TRY(w.alloc(ngates * esz));
-    gate_weights_kernel<F><<<blocks(ngates), kBlock, 0, cur_stream()>>>(L.arrays(), ngates, eqA->dptr, pb ? eqB->dptr : nullptr,
+    gate_weights_kernel<F><<<blocks(ngates), kBlock, 0, cur_stream()>>>((const uint32_t *)L.out.p, ngates, eqA->dptr, pb ? eqB->dptr : nullptr,
                                                         pb ? load_el<F>(alpha) : fe_zero<F>(), pb ? load_el<F>(beta) : fe_zero<F>(), w.p);
     int grid = reduce_grid_for(ngates);
     void *part;
