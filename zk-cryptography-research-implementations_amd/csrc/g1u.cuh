@@ -101,6 +101,79 @@ __device__ __forceinline__ void g1u_madd(G1XyzzU &acc, G1AffineU q, bool neg) {
     acc.y = y3;
 }
 
+// ---- XYZZ points kept in the internal form between kernels (partial sums, the bucket reduction arrays) ---------------------------
+// 4 x 64 B per point; infinity is the all-zero record (ZZ exactly 0), as in the stored form.
+static_assert(kXyzzUBytes == 4 * kUWords * 4, "msm_kernels.cuh");
+__device__ __forceinline__ G1XyzzU g1u_inf() {
+    G1XyzzU r;
+    r.x = u_zero<Fq381>(); r.y = u_zero<Fq381>(); r.zz = u_zero<Fq381>(); r.zzz = u_zero<Fq381>();
+    r.inf = true;
+    return r;
+}
+__device__ __forceinline__ G1XyzzU g1u_load_xyzz(const void *base, size_t idx) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(base) + idx * (4 * kUWords);
+    G1XyzzU r;
+    r.x = fqu_load(p);
+    r.y = fqu_load(p + kUWords);
+    r.zz = fqu_load(p + 2 * kUWords);
+    r.zzz = fqu_load(p + 3 * kUWords);
+    r.inf = u_is_exact_zero<Fq381>(r.zz);
+    return r;
+}
+__device__ __forceinline__ void g1u_store_xyzz(void *base, size_t idx, const G1XyzzU &a) {
+    uint32_t *p = reinterpret_cast<uint32_t *>(base) + idx * (4 * kUWords);
+    const G1XyzzU v = a.inf ? g1u_inf() : a;
+    fqu_store(p, v.x);
+    fqu_store(p + kUWords, v.y);
+    fqu_store(p + 2 * kUWords, v.zz);
+    fqu_store(p + 3 * kUWords, v.zzz);
+}
+// 2 a  (dbl-2008-s-1 on y^2 = x^3 + b).  Coordinates of `a` below 8 p; the result's below 6 p.
+__device__ __forceinline__ G1XyzzU g1u_dbl(const G1XyzzU &a) {
+    using F = Fq381;
+    if (a.inf) return a;
+    G1XyzzU o;
+    FqU u = uadd<F>(a.y, a.y);
+    FqU v = usqr<F>(u);
+    FqU w = umul<F>(u, v);
+    FqU s = umul<F>(a.x, v);
+    FqU xx = usqr<F>(a.x);
+    FqU m = uadd<F>(uadd<F>(xx, xx), xx);
+    FqU x3 = fqu_renorm(usub<F>(usqr<F>(m), uadd<F>(s, s)));      // < 2 p, so that it can be a subtrahend
+    o.x = x3;
+    o.y = usub<F>(umul<F>(m, usub<F>(s, x3)), umul<F>(w, a.y));
+    o.zz = umul<F>(v, a.zz);
+    o.zzz = umul<F>(w, a.zzz);
+    o.inf = false;
+    return o;
+}
+// a + b, both XYZZ (add-2008-s with the negated differences of g1u_madd; 12 products + 2 squarings, Y3 as one dual product).
+// Coordinates of the operands below 8 p; the result's below 8 p.  P = Q and P = -Q are detected from ZZ3 = 0 mod p.
+__device__ __forceinline__ G1XyzzU g1u_add(const G1XyzzU &a, const G1XyzzU &b) {
+    using F = Fq381;
+    if (a.inf) return b;
+    if (b.inf) return a;
+    FqU u1 = umul<F>(a.x, b.zz), u2 = umul<F>(b.x, a.zz);
+    FqU s1 = umul<F>(a.y, b.zzz), s2 = umul<F>(b.y, a.zzz);
+    FqU pn = usub<F>(u1, u2);                          // P' = U1 - U2
+    FqU rn = usub<F>(s1, s2);                          // R' = S1 - S2
+    FqU pp = usqr<F>(pn);
+    FqU pppn = umul<F>(pn, pp);
+    FqU qq = umul<F>(u1, pp);
+    FqU zz3 = umul<F>(umul<F>(a.zz, b.zz), pp);
+    if (u_is_zero_mod_p<F>(zz3)) {                     // P' = 0: the same x coordinate
+        if (fqu_is_zero(pn)) return fqu_is_zero(rn) ? g1u_dbl(a) : g1u_inf();
+    }
+    G1XyzzU o;
+    FqU x3 = usub<F>(uadd<F>(usqr<F>(rn), pppn), uadd<F>(qq, qq));
+    o.y = umul2<F>(rn, usub<F>(x3, qq), s1, pppn);
+    o.zzz = usub<F>(u_zero<F>(), umul<F>(umul<F>(a.zzz, b.zzz), pppn));
+    o.zz = zz3;
+    o.x = x3;
+    o.inf = false;
+    return o;
+}
+
 // internal accumulator -> stored XYZZ (canonical 32-bit Montgomery limbs)
 __device__ __forceinline__ G1Xyzz g1u_to_std(const G1XyzzU &a) {
     using F = Fq381;

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) msm_bucket_sum_kernel(const void *__restr
             p = pn;
         }
     }
-    g1_store_xyzz(partials, t, g1u_to_std(acc));
+    g1u_store_xyzz(partials, t, acc);                       // internal form: the combination and reduction kernels stay in it
 }
 
 // stored affine bases (96 B) -> internal form (128 B per point)

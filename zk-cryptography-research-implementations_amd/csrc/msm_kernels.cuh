@@ -441,6 +441,7 @@ int launch_msm_bucket_sum(const void *bases, const uint32_t *sorted, const uint6
 int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_starts, const uint32_t *out_starts, size_t nbuckets,
                                 unsigned group, uint32_t nout, void *out_partials, hipStream_t s);
 constexpr size_t kBaseUBytes = 128;   // one pre-converted affine point (g1u.cuh)
+constexpr size_t kXyzzUBytes = 256;   // one XYZZ point in the internal form (g1u.cuh): partial sums, reduction arrays
 int launch_msm_plain_level(void *A, void *B, unsigned nwin, unsigned cm1, unsigned k, size_t hh, size_t lh, hipStream_t s);
 int launch_msm_gather_cd(const void *A, const void *B, unsigned nwin, unsigned cm1, unsigned k, unsigned mbits, void *X, hipStream_t s);
 int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsigned mbits, void *out, hipStream_t s);

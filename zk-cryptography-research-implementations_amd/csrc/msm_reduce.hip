@@ -1,6 +1,9 @@
 // msm_reduce.hip -- Pippenger bucket combination and the log-depth weighted bucket reduction (own TU).
+// Every array between the bucket kernel and the last kernel of the reduction holds XYZZ points in the internal 29-bit-limb
+// form (g1u.cuh, 256 B per point): no conversion per product, which is what the late, single-lane levels are made of.
 #include "context.h"
 #include "msm_kernels.cuh"
+#include "g1u.cuh"
 
 namespace zk {
 
@@ -19,9 +22,9 @@ __global__ void __launch_bounds__(256) msm_partials_regroup_kernel(const void *_
     uint32_t first = in_starts[b] + (t - out_starts[b]) * group;
     uint32_t end = in_starts[b + 1];
     if (first + group < end) end = first + group;
-    G1Xyzz acc = g1_load_xyzz(in_partials, first);
-    for (uint32_t e = first + 1; e < end; e++) acc = g1_add(acc, g1_load_xyzz(in_partials, e));
-    g1_store_xyzz(out_partials, t, acc);
+    G1XyzzU acc = g1u_load_xyzz(in_partials, first);
+    for (uint32_t e = first + 1; e < end; e++) acc = g1u_add(acc, g1u_load_xyzz(in_partials, e));
+    g1u_store_xyzz(out_partials, t, acc);
 }
 
 // bucket (w, b) = sum of its segments' partials, written to slot b of window w in the 2^(c-1)-slot reduction array A
@@ -33,9 +36,9 @@ __global__ void __launch_bounds__(256) msm_bucket_combine_kernel(const void *__r
     if (id >= (size_t)nwin * nb) return;
     unsigned w = id / nb, b = id % nb;
     uint32_t s0 = seg_starts[id], s1 = seg_starts[id + 1];
-    G1Xyzz acc = g1_xyzz_inf();
-    for (uint32_t s = s0; s < s1; s++) acc = g1_add(acc, g1_load_xyzz(partials, s));
-    g1_store_xyzz(A, ((size_t)w << (c - 1)) + b, acc);
+    G1XyzzU acc = g1u_inf();
+    for (uint32_t s = s0; s < s1; s++) acc = g1u_add(acc, g1u_load_xyzz(partials, s));
+    g1u_store_xyzz(A, ((size_t)w << (c - 1)) + b, acc);
 }
 
 // step 4: one halving level of  sum_b b A[b]  over the 2^(c-1) slots of every window, in place (half = current length / 2):
@@ -53,12 +56,12 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(void *__restrict_
     if (second) id -= work;
     size_t w = id / half, b = id % half;
     size_t base = w << (c - 1);
-    G1Xyzz ahi = g1_load_xyzz(A, base + b + half);
+    G1XyzzU ahi = g1u_load_xyzz(A, base + b + half);
     if (!second) {
-        g1_store_xyzz(A, base + b, g1_add(g1_load_xyzz(A, base + b), ahi));
+        g1u_store_xyzz(A, base + b, g1u_add(g1u_load_xyzz(A, base + b), ahi));
     } else {
-        G1Xyzz rlo = g1_load_xyzz(R, base + b), rhi = g1_load_xyzz(R, base + b + half);
-        g1_store_xyzz(R, base + b, g1_add(ahi, g1_dbl(g1_add(rlo, rhi))));
+        G1XyzzU rlo = g1u_load_xyzz(R, base + b), rhi = g1u_load_xyzz(R, base + b + half);
+        g1u_store_xyzz(R, base + b, g1u_add(ahi, g1u_dbl(g1u_add(rlo, rhi))));
     }
 }
 
@@ -77,13 +80,13 @@ __global__ void __launch_bounds__(256) msm_plain_level_kernel(void *__restrict__
     if (id < work1) {
         size_t w = id / (hh * L), r = id % (hh * L);
         size_t base = (w << cm1) + r;
-        g1_store_xyzz(A, base, g1_add(g1_load_xyzz(A, base), g1_load_xyzz(A, base + hh * L)));
+        g1u_store_xyzz(A, base, g1u_add(g1u_load_xyzz(A, base), g1u_load_xyzz(A, base + hh * L)));
     } else if (id < work1 + work2) {
         id -= work1;
         size_t w = id / (H * lh), r = id % (H * lh);
         size_t h = r / lh, l = r % lh;
         size_t base = (w << cm1) + h * L + l;
-        g1_store_xyzz(B, base, g1_add(g1_load_xyzz(B, base), g1_load_xyzz(B, base + lh)));
+        g1u_store_xyzz(B, base, g1u_add(g1u_load_xyzz(B, base), g1u_load_xyzz(B, base + lh)));
     }
 }
 // compact the two short arrays, zero-padded to M = 2^mbits entries: X[0][w][l] = C[l] = A[w][l],  X[1][w][h] = D[h] = B[w][h L]
@@ -93,26 +96,27 @@ __global__ void msm_gather_cd_kernel(const void *__restrict__ A, const void *__r
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 2 * (size_t)nwin * M) return;
     size_t p = id / ((size_t)nwin * M), r = id % ((size_t)nwin * M), w = r / M, i = r % M;
-    G1Xyzz v = g1_xyzz_inf();
-    if (p == 0) { if (i < L) v = g1_load_xyzz(A, (w << cm1) + i); }
-    else if (i < H) v = g1_load_xyzz(B, (w << cm1) + i * L);
-    g1_store_xyzz(X, id, v);
+    G1XyzzU v = g1u_inf();
+    if (p == 0) { if (i < L) v = g1u_load_xyzz(A, (w << cm1) + i); }
+    else if (i < H) v = g1u_load_xyzz(B, (w << cm1) + i * L);
+    g1u_store_xyzz(X, id, v);
 }
 // out[3 w .. 3 w + 2] = sum_l l C[l], sum_l C[l], sum_h h D[h]  (R_l[0], A_l[0], R_h[0] of the weighted reductions)
 __global__ void msm_two_stage_out_kernel(const void *__restrict__ X, const void *__restrict__ Y, unsigned nwin, unsigned mbits, void *__restrict__ out) {
     unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwin) return;
     const size_t M = (size_t)1 << mbits;
-    g1_store_xyzz(out, 3 * (size_t)w, g1_load_xyzz(Y, (size_t)w * M));
-    g1_store_xyzz(out, 3 * (size_t)w + 1, g1_load_xyzz(X, (size_t)w * M));
-    g1_store_xyzz(out, 3 * (size_t)w + 2, g1_load_xyzz(Y, ((size_t)nwin + w) * M));
+    // the results leave the internal form here (stored XYZZ, canonical limbs) for the host's window combination
+    g1_store_xyzz(out, 3 * (size_t)w, g1u_to_std(g1u_load_xyzz(Y, (size_t)w * M)));
+    g1_store_xyzz(out, 3 * (size_t)w + 1, g1u_to_std(g1u_load_xyzz(X, (size_t)w * M)));
+    g1_store_xyzz(out, 3 * (size_t)w + 2, g1u_to_std(g1u_load_xyzz(Y, ((size_t)nwin + w) * M)));
 }
 
 __global__ void msm_window_sums_kernel(const void *__restrict__ A, const void *__restrict__ R, unsigned nwin, unsigned c, void *__restrict__ out) {
     unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwin) return;
     size_t base = (size_t)w << (c - 1);
-    g1_store_xyzz(out, w, g1_add(g1_load_xyzz(R, base), g1_load_xyzz(A, base)));
+    g1_store_xyzz(out, w, g1u_to_std(g1u_add(g1u_load_xyzz(R, base), g1u_load_xyzz(A, base))));
 }
 
 int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_starts, const uint32_t *out_starts, size_t nbuckets,

@@ -201,8 +201,8 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     }
     ZK_TRY(ev.mark());
     // bucket sums
-    ZK_TRY(partials.alloc(((size_t)nseg ? nseg : 1) * sizeof(G1Xyzz)));
-    size_t red_bytes = ((size_t)nwin << (c - 1)) * sizeof(G1Xyzz);
+    ZK_TRY(partials.alloc(((size_t)nseg ? nseg : 1) * kXyzzUBytes));      // XYZZ in the internal form (g1u.cuh) from here on
+    size_t red_bytes = ((size_t)nwin << (c - 1)) * kXyzzUBytes;
     ZK_TRY(A.alloc(red_bytes));
     ZK_TRY(R.alloc(red_bytes));
     ZK_HIP(hipMemsetAsync(A.p, 0, red_bytes, cur_stream()));     // all-zero XYZZ = infinity (ZZ = 0)
@@ -225,7 +225,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         msm_regroup_scan_kernel<<<1, kSortBlock, 0, cur_stream()>>>(cur_starts, nbuckets, kGroup, (uint32_t *)ns.p);
         ZK_HIP(hipGetLastError());
         ZK_HIP(zk::memcpy_on_stream(tail, (uint32_t *)ns.p + nbuckets, 8, hipMemcpyDeviceToHost));
-        ZK_TRY(np.alloc(((size_t)tail[0] ? tail[0] : 1) * sizeof(G1Xyzz)));
+        ZK_TRY(np.alloc(((size_t)tail[0] ? tail[0] : 1) * kXyzzUBytes));
         ZK_TRY(launch_msm_partials_regroup(cur_partials, cur_starts, (const uint32_t *)ns.p, nbuckets, kGroup, tail[0], np.p, cur_stream()));
         cur_partials = np.p;
         cur_starts = (const uint32_t *)ns.p;
@@ -243,7 +243,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
             ZK_TRY(launch_msm_plain_level(A.p, R.p, nwin, cm1, k, hh, lh, cur_stream()));
         }
         DevBuf X, Y, out3;                                  // X: the arrays C (per window) then D, zero-padded; Y: their R arrays
-        const size_t small_bytes = 2 * ((size_t)nwin << mbits) * sizeof(G1Xyzz);
+        const size_t small_bytes = 2 * ((size_t)nwin << mbits) * kXyzzUBytes;
         ZK_TRY(X.alloc(small_bytes));
         ZK_TRY(Y.alloc(small_bytes));
         ZK_TRY(out3.alloc(3 * (size_t)nwin * sizeof(G1Xyzz)));
