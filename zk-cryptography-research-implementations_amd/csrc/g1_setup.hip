@@ -1,6 +1,7 @@
 // g1_setup.hip -- setup-side G1 kernels: fixed-base scalar mul, batch normalisation, pair sums, synthetic bases (own TU).
 #include "context.h"
 #include "msm_kernels.cuh"
+#include "g1u.cuh"
 
 namespace zk {
 
@@ -12,29 +13,57 @@ __global__ void __launch_bounds__(256) g1_pair_add_kernel(const void *__restrict
     g1_store_xyzz(out_xyzz, k, g1_madd(g1_from_affine(g1_load_affine(in_affine, k)), g1_load_affine(in_affine, k + half)));
 }
 
-// out[k] = 2^c * in[k]: the window-shifted copies of a small base set (batched opening MSMs, zkmle_kzg.hip)
-__global__ void __launch_bounds__(256) g1_shift_kernel(const void *__restrict__ in_affine, size_t n, unsigned c, void *__restrict__ out_xyzz) {
+// the same on stored XYZZ input (the short levels are summed in a chain and normalised together at the end)
+__global__ void __launch_bounds__(256) g1_pair_add_xyzz_kernel(const void *__restrict__ in_xyzz, size_t half, void *__restrict__ out_xyzz) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    G1Xyzz p = g1_from_affine(g1_load_affine(in_affine, k));
-    for (unsigned i = 0; i < c; i++) p = g1_dbl(p);
-    g1_store_xyzz(out_xyzz, k, p);
+    if (k >= half) return;
+    g1_store_xyzz(out_xyzz, k, g1_add(g1_load_xyzz(in_xyzz, k), g1_load_xyzz(in_xyzz, k + half)));
 }
 
-// fixed-base scalar multiplication  out[i] = [s_i] G  with a byte-window table of G
-// (table[j * 256 + v] = [v * 256^j] G, affine, 32 x 256 entries): 32 mixed adds per point
-// (compute_g1_powers_of_tau trusted_setup.rs:51-60 does one 255-bit double-and-add per point).
-__global__ void __launch_bounds__(256) fixed_base_mul_kernel(const void *__restrict__ scalars, size_t n, const void *__restrict__ table,
+// out[k] = 2^c * in[k]: the window-shifted copies of a small base set (batched opening MSMs, zkmle_kzg.hip).  The input is
+// stored affine (`in_is_xyzz` = 0) or stored XYZZ (a previous shift, not normalised in between); the doublings run in the
+// internal form.
+__global__ void __launch_bounds__(256) g1_shift_kernel(const void *__restrict__ in, int in_is_xyzz, size_t n, unsigned c, void *__restrict__ out_xyzz) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    G1Xyzz p = in_is_xyzz ? g1_load_xyzz(in, k) : g1_from_affine(g1_load_affine(in, k));
+    if (g1_is_inf(p)) { g1_store_xyzz(out_xyzz, k, g1_xyzz_inf()); return; }
+    G1XyzzU q;
+    q.x = u_from_std<Fq381>(p.x); q.y = u_from_std<Fq381>(p.y); q.zz = u_from_std<Fq381>(p.zz); q.zzz = u_from_std<Fq381>(p.zzz);
+    q.inf = false;
+    for (unsigned i = 0; i < c; i++) q = g1u_dbl(q);
+    g1_store_xyzz(out_xyzz, k, g1u_to_std(q));
+}
+
+// fixed-base scalar multiplication  out[i] = [s_i] G  with a 16-bit-window table of G in the internal form
+// (table16[j * 65536 + v] = [v * 65536^j] G, 16 x 65536 pre-converted affine points, 128 MiB): 16 mixed additions per point
+// (compute_g1_powers_of_tau trusted_setup.rs:51-60 does one 255-bit double-and-add per point; r1 started with a byte-window
+// table and 32 additions per point: 88 ms for 2^24 points).
+__global__ void __launch_bounds__(256) fixed_base_mul_kernel(const void *__restrict__ scalars, size_t n, const void *__restrict__ table16,
                                                              void *__restrict__ out_xyzz) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fe<Fr381> k = fe_to_canonical<Fr381>(fe_load<Fr381>(scalars, i));
-    G1Xyzz acc = g1_xyzz_inf();
-    for (int j = 0; j < 32; j++) {
-        unsigned v = (k.l[j >> 2] >> (8 * (j & 3))) & 0xffu;
-        if (v) acc = g1_madd(acc, g1_load_affine(table, (size_t)j * 256 + v));
+    G1XyzzU acc = g1u_inf();
+    for (int j = 0; j < 16; j++) {
+        unsigned v = (k.l[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+        if (v) g1u_madd(acc, g1u_load_affine(table16, (size_t)j * 65536 + v), false);
     }
-    g1_store_xyzz(out_xyzz, i, acc);
+    g1_store_xyzz(out_xyzz, i, g1u_to_std(acc));
+}
+// the 16-bit-window table from the byte-window table (table8[j * 256 + v] = [v * 256^j] G, stored affine, (0, 0) = infinity):
+// entry (j, v) = table8[2 j][v & 255] + table8[2 j + 1][v >> 8]
+__global__ void __launch_bounds__(256) fixed_table16_kernel(const void *__restrict__ table8, void *__restrict__ out_xyzz) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)16 * 65536) return;
+    unsigned j = (unsigned)(id >> 16), v = (unsigned)(id & 0xffffu), lo = v & 255u, hi = v >> 8;
+    G1Xyzz acc = g1_xyzz_inf();
+    if (lo) acc = g1_from_affine(g1_load_affine(table8, (size_t)(2 * j) * 256 + lo));
+    if (hi) {
+        G1Affine q = g1_load_affine(table8, (size_t)(2 * j + 1) * 256 + hi);
+        acc = lo ? g1_madd(acc, q) : g1_from_affine(q);
+    }
+    g1_store_xyzz(out_xyzz, id, acc);
 }
 
 // batch normalisation XYZZ -> affine: each lane owns `per` consecutive points and shares one
@@ -64,6 +93,36 @@ __global__ void __launch_bounds__(256) batch_to_affine_kernel(const void *__rest
             a.y = fe_mul<Fq>(p.y, fe_mul<Fq>(t_k, p.zz));
         }
         g1_store_affine(affine, lo + k, a);
+    }
+}
+
+// the same for large arrays: lane t owns the points t, t + T, t + 2 T, ... (coalesced across lanes), keeps its running prefix
+// products in `scratch` (one Fq element per point) instead of registers, and so shares one inversion among `n / T` points
+// (64 instead of 16: the inversion is ~570 products, more than the 9 useful ones per point of the short batches).
+__global__ void __launch_bounds__(256) batch_to_affine_strided_kernel(const void *__restrict__ xyzz, size_t n, size_t T, void *__restrict__ scratch,
+                                                                      void *__restrict__ affine) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T || t >= n) return;
+    FqE run = fe_one<Fq>();
+    for (size_t i = t; i < n; i += T) {
+        G1Xyzz p = g1_load_xyzz(xyzz, i);
+        fe_store<Fq>(scratch, i, run);
+        if (!g1_is_inf(p)) run = fe_mul<Fq>(run, fe_mul<Fq>(p.zz, p.zzz));
+    }
+    FqE inv = fe_inv<Fq>(run);
+    for (size_t k = (n - t + T - 1) / T; k-- > 0;) {
+        size_t i = t + k * T;
+        G1Xyzz p = g1_load_xyzz(xyzz, i);
+        G1Affine a;
+        if (g1_is_inf(p)) {
+            a.x = fe_zero<Fq>(); a.y = fe_zero<Fq>();
+        } else {
+            FqE t_k = fe_mul<Fq>(inv, fe_load<Fq>(scratch, i));     // 1 / (zz * zzz)
+            inv = fe_mul<Fq>(inv, fe_mul<Fq>(p.zz, p.zzz));
+            a.x = fe_mul<Fq>(p.x, fe_mul<Fq>(t_k, p.zzz));
+            a.y = fe_mul<Fq>(p.y, fe_mul<Fq>(t_k, p.zz));
+        }
+        g1_store_affine(affine, i, a);
     }
 }
 
@@ -114,17 +173,39 @@ int launch_g1_pair_add(const void *in_affine, size_t half, void *out_xyzz, hipSt
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
-int launch_g1_shift(const void *in_affine, size_t n, unsigned c, void *out_xyzz, hipStream_t s) {
-    g1_shift_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(in_affine, n, c, out_xyzz);
+int launch_g1_pair_add_xyzz(const void *in_xyzz, size_t half, void *out_xyzz, hipStream_t s) {
+    g1_pair_add_xyzz_kernel<<<(unsigned)((half + 255) / 256), 256, 0, s>>>(in_xyzz, half, out_xyzz);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
-int launch_fixed_base_mul(const void *scalars, size_t n, const void *table, void *out_xyzz, hipStream_t s) {
-    fixed_base_mul_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(scalars, n, table, out_xyzz);
+int launch_g1_shift(const void *in, int in_is_xyzz, size_t n, unsigned c, void *out_xyzz, hipStream_t s) {
+    g1_shift_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(in, in_is_xyzz, n, c, out_xyzz);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int launch_fixed_base_mul(const void *scalars, size_t n, const void *table16, void *out_xyzz, hipStream_t s) {
+    fixed_base_mul_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(scalars, n, table16, out_xyzz);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int launch_fixed_table16(const void *table8, void *out_xyzz, hipStream_t s) {
+    fixed_table16_kernel<<<16 * 65536 / 256, 256, 0, s>>>(table8, out_xyzz);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
 int launch_batch_to_affine(const void *xyzz, size_t n, void *affine, hipStream_t s) {
+    if (n >= ((size_t)1 << 21)) {                       // long batches, prefix products in pooled scratch (reused in stream order)
+        size_t per = n >> 16;
+        if (per > 64) per = 64;
+        const size_t T = (n + per - 1) / per;
+        void *scratch = nullptr;
+        ZK_TRY(pool_alloc(n * sizeof(FqE), &scratch));
+        batch_to_affine_strided_kernel<<<(unsigned)((T + 255) / 256), 256, 0, s>>>(xyzz, n, T, scratch, affine);
+        hipError_t e = hipGetLastError();
+        pool_free(scratch);
+        ZK_HIP(e);
+        return ZK_OK;
+    }
     size_t threads = (n + kNormPer - 1) / kNormPer;
     batch_to_affine_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(xyzz, n, affine);
     ZK_HIP(hipGetLastError());

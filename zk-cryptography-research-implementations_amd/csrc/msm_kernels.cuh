@@ -447,11 +447,13 @@ int launch_msm_gather_cd(const void *A, const void *B, unsigned nwin, unsigned c
 int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsigned mbits, void *out, hipStream_t s);
 int launch_msm_window_sums(const void *A, const void *R, unsigned nwin, unsigned c, void *out, hipStream_t s);
 int launch_g1_bases_to_u(const void *affine, size_t n, void *out_u, hipStream_t s);
-int launch_g1_shift(const void *in_affine, size_t n, unsigned c, void *out_xyzz, hipStream_t s);   // out = 2^c * in
+int launch_g1_shift(const void *in, int in_is_xyzz, size_t n, unsigned c, void *out_xyzz, hipStream_t s);   // out = 2^c * in (stored affine or XYZZ in)
 int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, hipStream_t s);
 int launch_msm_reduce_level(void *A, void *R, unsigned nwin, unsigned c, size_t half, hipStream_t s);
 int launch_g1_pair_add(const void *in_affine, size_t half, void *out_xyzz, hipStream_t s);
-int launch_fixed_base_mul(const void *scalars, size_t n, const void *table, void *out_xyzz, hipStream_t s);
+int launch_g1_pair_add_xyzz(const void *in_xyzz, size_t half, void *out_xyzz, hipStream_t s);
+int launch_fixed_base_mul(const void *scalars, size_t n, const void *table16, void *out_xyzz, hipStream_t s);   // table16: pre-converted (g1u.cuh)
+int launch_fixed_table16(const void *table8, void *out_xyzz, hipStream_t s);
 int launch_batch_to_affine(const void *xyzz, size_t n, void *affine, hipStream_t s);
 int launch_synthetic_bases(const G1Affine &g, const G1Affine &dstep, const Fe<Fr381> &a_canon, const Fe<Fr381> &d_canon, size_t n,
                            unsigned per, void *out_xyzz, hipStream_t s);

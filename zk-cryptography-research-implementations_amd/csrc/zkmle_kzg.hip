@@ -335,7 +335,8 @@ int normalize_to_bases(const void *d_xyzz, size_t n, zk_g1_bases **out) {
     return ZK_OK;
 }
 
-// byte-window table of the generator: table[j * 256 + v] = [v * 256^j] G, built once per device on the host
+// window table of the generator for the fixed-base kernel (g1_setup.hip), built once per device: the byte-window table
+// table8[j * 256 + v] = [v * 256^j] G on the host (8 K points), its 16-bit-window form on the device
 std::mutex g_tab_mu;
 std::vector<void *> g_gen_table;
 int generator_table(const void **out) {
@@ -367,9 +368,20 @@ int generator_table(const void **out) {
             aff[i].x = fe_mul<Fq>(tab[i].x, fe_mul<Fq>(t, tab[i].zzz));
             aff[i].y = fe_mul<Fq>(tab[i].y, fe_mul<Fq>(t, tab[i].zz));
         }
+        // 16-bit windows on the device: pairs of byte entries added, normalised, converted to the internal form (once per device)
+        const size_t n16 = (size_t)16 * 65536;
+        DevBuf t8, xyzz, aff16;
+        ZK_TRY(t8.alloc(aff.size() * sizeof(G1Affine)));
+        ZK_HIP(zk::memcpy_on_stream(t8.p, aff.data(), aff.size() * sizeof(G1Affine), hipMemcpyHostToDevice));
+        ZK_TRY(xyzz.alloc(n16 * sizeof(G1Xyzz)));
+        ZK_TRY(aff16.alloc(n16 * sizeof(G1Affine)));
         void *d = nullptr;
-        ZK_HIP(hipMalloc(&d, aff.size() * sizeof(G1Affine)));
-        ZK_HIP(zk::memcpy_on_stream(d, aff.data(), aff.size() * sizeof(G1Affine), hipMemcpyHostToDevice));
+        ZK_HIP(hipMalloc(&d, n16 * kBaseUBytes));
+        int rc = launch_fixed_table16(t8.p, xyzz.p, cur_stream());
+        if (rc == ZK_OK) rc = launch_batch_to_affine(xyzz.p, n16, aff16.p, cur_stream());
+        if (rc == ZK_OK) rc = launch_g1_bases_to_u(aff16.p, n16, d, cur_stream());
+        if (rc == ZK_OK && hipStreamSynchronize(cur_stream()) != hipSuccess) rc = ZK_E_HIP;
+        if (rc != ZK_OK) { (void)hipFree(d); return rc; }
         g_gen_table[dev] = d;
     }
     *out = g_gen_table[dev];
@@ -500,7 +512,12 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
     key->level.assign(key->nvars + 1, nullptr);
     const zk_g1_bases *cur = g1;
     int rc = ZK_OK;
-    for (size_t t = 1; t <= key->nvars && rc == ZK_OK; t++) {
+    // levels of more than kChainLen points: pair sums of the previous (affine) level, normalised one by one.  From there on the
+    // sums stay XYZZ, level after level end to end in one buffer, and are normalised together: a normalisation is one ~1.3 ms
+    // inversion chain whatever its size, and there are up to 13 such levels.
+    const size_t kChainLen = 4096;
+    size_t t = 1;
+    for (; t <= key->nvars && rc == ZK_OK && cur->n / 2 > kChainLen; t++) {
         size_t half = cur->n / 2;
         DevBuf xyzz;
         rc = xyzz.alloc(half * sizeof(G1Xyzz));
@@ -510,15 +527,37 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
         rc = normalize_to_bases(xyzz.p, half, &key->level[t]);
         cur = key->level[t];
     }
+    if (rc == ZK_OK && t <= key->nvars) {
+        const size_t first = cur->n / 2, total = 2 * first - 1;         // sizes first, first / 2, ..., 1
+        DevBuf chain, aff;
+        rc = chain.alloc(total * sizeof(G1Xyzz));
+        if (rc == ZK_OK) rc = aff.alloc(total * sizeof(G1Affine));
+        if (rc == ZK_OK) rc = launch_g1_pair_add(cur->dptr, first, chain.p, cur_stream());
+        size_t off = 0;
+        for (size_t half = first / 2; half >= 1 && rc == ZK_OK; half /= 2) {
+            rc = launch_g1_pair_add_xyzz((const char *)chain.p + off * sizeof(G1Xyzz), half, (char *)chain.p + (off + 2 * half) * sizeof(G1Xyzz), cur_stream());
+            off += 2 * half;
+        }
+        if (rc == ZK_OK) rc = launch_batch_to_affine(chain.p, total, aff.p, cur_stream());
+        off = 0;
+        for (size_t len = first; len >= 1 && rc == ZK_OK; len /= 2, t++) {
+            rc = bases_alloc(len, &key->level[t]);
+            if (rc == ZK_OK && hipMemcpyAsync(key->level[t]->dptr, (const char *)aff.p + off * sizeof(G1Affine), len * sizeof(G1Affine), hipMemcpyDeviceToDevice,
+                                              cur_stream()) != hipSuccess) rc = ZK_E_HIP;
+            off += len;
+        }
+        if (rc == ZK_OK && hipStreamSynchronize(cur_stream()) != hipSuccess) rc = ZK_E_HIP;
+    }
     if (rc == ZK_OK && key->nvars >= 2) {                   // with one variable there is a single 1-term MSM: nothing to batch
         key->small_bits = (unsigned)(key->nvars - 1 < open_batch_bits() ? key->nvars - 1 : open_batch_bits());
         key->small_t0 = key->nvars - key->small_bits;
         const size_t nlev = key->small_bits + 1, total = ((size_t)1 << nlev) - 1;
         key->small_c = pick_window((size_t)1 << key->small_bits);
         const unsigned c = (unsigned)key->small_c, nwin = (256 + c - 1) / c;
-        DevBuf aff, xyzz;                                   // the levels end to end, then shifted window by window
+        DevBuf aff, xall, affall;                           // the levels end to end; their shifted copies 2^(c w) B, w = 1 .. nwin - 1
         rc = aff.alloc(total * sizeof(G1Affine));
-        if (rc == ZK_OK) rc = xyzz.alloc(total * sizeof(G1Xyzz));
+        if (rc == ZK_OK) rc = xall.alloc((size_t)(nwin - 1) * total * sizeof(G1Xyzz));
+        if (rc == ZK_OK) rc = affall.alloc((size_t)(nwin - 1) * total * sizeof(G1Affine));
         hipError_t e = hipSuccess;
         if (rc == ZK_OK) e = hipMalloc(&key->small_u, (size_t)nwin * total * kBaseUBytes);
         for (size_t j = 0; j < nlev && rc == ZK_OK && e == hipSuccess; j++) {
@@ -527,11 +566,15 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
             e = hipMemcpyAsync((char *)aff.p + off * sizeof(G1Affine), lv->dptr, lv->n * sizeof(G1Affine), hipMemcpyDeviceToDevice, cur_stream());
         }
         if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
-        for (unsigned w = 0; w < nwin && rc == ZK_OK; w++) {
-            rc = launch_g1_bases_to_u(aff.p, total, (char *)key->small_u + (size_t)w * total * kBaseUBytes, cur_stream());
-            if (rc == ZK_OK && w + 1 < nwin) rc = launch_g1_shift(aff.p, total, c, xyzz.p, cur_stream());
-            if (rc == ZK_OK && w + 1 < nwin) rc = launch_batch_to_affine(xyzz.p, total, aff.p, cur_stream());
+        // window 0 as it is; every further window is c doublings of the previous one (XYZZ to XYZZ), and all of them are
+        // normalised in ONE batch (r1: one normalisation per window cost its ~1.3 ms inversion latency 15 times)
+        if (rc == ZK_OK) rc = launch_g1_bases_to_u(aff.p, total, key->small_u, cur_stream());
+        for (unsigned w = 1; w < nwin && rc == ZK_OK; w++) {
+            const void *src = w == 1 ? aff.p : (const void *)((const char *)xall.p + (size_t)(w - 2) * total * sizeof(G1Xyzz));
+            rc = launch_g1_shift(src, w == 1 ? 0 : 1, total, c, (char *)xall.p + (size_t)(w - 1) * total * sizeof(G1Xyzz), cur_stream());
         }
+        if (rc == ZK_OK && nwin > 1) rc = launch_batch_to_affine(xall.p, (size_t)(nwin - 1) * total, affall.p, cur_stream());
+        if (rc == ZK_OK && nwin > 1) rc = launch_g1_bases_to_u(affall.p, (size_t)(nwin - 1) * total, (char *)key->small_u + total * kBaseUBytes, cur_stream());
         if (rc == ZK_OK && hipStreamSynchronize(cur_stream()) != hipSuccess) rc = ZK_E_HIP;
     }
     if (rc != ZK_OK) { zk_kzg_opening_key_free(key.release()); return rc; }
