@@ -290,3 +290,25 @@ def test_msm_and_open_on_a_nonblocking_user_stream(zk):
         assert O.g1_affine_ints(got) == M.g1_mul(M.G1, k)
     finally:
         assert L.zk_set_stream(None) == 0
+
+
+def test_setup_with_infinite_points_2p21(zk):
+    """tau_0 = 1 and tau_3 = 0 make three quarters of the Lagrange coefficients zero: the long-batch normalisation, the pre-summed
+    levels and the MSMs all see points at infinity at a size that takes the large-array kernels"""
+    rng = random.Random(2121)
+    nv = 21
+    taus_i = [rng.randrange(R) for _ in range(nv)]
+    taus_i[0], taus_i[3] = 1, 0
+    taus = zk.from_ints(0, taus_i)
+    setup = zk.TrustedSetup.initialize_setup(taus)
+    pts = setup.g1_powers_of_tau.points()
+    inf = ~pts.any(axis=1)
+    assert int(inf.sum()) == 3 * (1 << (nv - 2))
+    assert not inf[(1 << (nv - 1)) + 5] and inf[5]                     # index bit (n-1) = variable 0 must be 1, variable 3 must be 0
+    poly = zk.MultilinearPolynomial.random(0, 1 << nv, 777)
+    f_tau = O.to_ints(O.FR381, O.evaluate(O.FR381, poly.evaluated_values, taus))[0]
+    c = zk.MultilinearKZG.commit_to_polynomial(poly, setup)
+    assert O.g1_affine_ints(c) == M.g1_mul(M.G1, f_tau)
+    opening = zk.from_ints(0, [rng.randrange(R) for _ in range(nv)])
+    proof = zk.MultilinearKZG.open_and_prove(poly, setup, opening)
+    assert zk.MultilinearKZG.verify(setup, c, opening, proof) is True
