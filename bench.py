@@ -45,11 +45,25 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     _lib.check(zk.lib().zk_init(local_rank))
+    backend_note = None
     if world > 1:
         if args.rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)                      # the first collective builds the communicator: fail here, not mid-run
+                torch.cuda.synchronize()
+            except Exception as e:                          # noqa: BLE001  -- keep the headline line: the collectives go over gloo
+                backend_note = f"nccl (RCCL) unavailable, collectives over gloo with host staging: {e!r}"[:300]
+                try:
+                    dist.destroy_process_group()
+                except Exception:                           # noqa: BLE001
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo")
+                args.rehearse = True                        # host-staged tensors from here on (each rank keeps its own GPU)
 
     field = zk.FR381
     n = 1 << args.log_n
@@ -121,6 +135,8 @@ def main():
         with open(pmc) as f:
             result["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
         result["roofline"]["traffic_source"] = "profiles/r1/fold_2p24_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)"
+    if backend_note:
+        result["collectives"] = backend_note
     if world > 1:
         try:                                               # a failure in a secondary leg must not cost the headline line
             result["exchange"] = sumcheck_round_exchange(zk, table, out, r, world, local_rank, args.rehearse)
