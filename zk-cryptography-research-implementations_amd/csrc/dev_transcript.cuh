@@ -370,6 +370,7 @@ template <class F> __global__ void __launch_bounds__(128) limbs_finish_kernel(Li
 // transcript step in wave 0 and broadcasts the challenge through LDS.  Same arithmetic, same bytes absorbed.
 constexpr int kTailBlock = 512;
 constexpr size_t kTailLen = 4 * (size_t)kTailBlock;
+constexpr int kTailSplit = 512;      // (pair index, table) lanes of a split round: 2 x 32 B each in LDS
 
 struct TailArgs {
     SumPolyTables tabs;      // in[k]: current tables of `len` entries
@@ -402,22 +403,81 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
         Wide<F> acc[NFAC + 1];
 #pragma unroll
         for (int t = 0; t <= NFAC; t++) acc[t] = wide_zero<F>();
-        if (tid < q) {
-            const Multiplier<F> mr(r);
-            for (int p = 0; p < a.nprod; p++) {
-                Fe<F> lo[NFAC], hi[NFAC];
+        // A lane's share of a round is a chain of products (14 for two products of two factors) and the round lasts as long as
+        // that chain, so idle lanes take over parts of it once the table is short: one lane per (pair index, product) while
+        // q * nprod lanes exist, one lane per (pair index, table) -- the factors then meet through LDS -- while q * ntab <= kTailSplit.
+        int split = 0;
+        if constexpr (NFAC == 2) {
+            if (q * (size_t)a.ntab <= (size_t)kTailSplit) split = 2;
+            else if (q * (size_t)a.nprod <= (size_t)kTailBlock) split = 1;
+        }
+        if (split == 0) {
+            if (tid < q) {
+                const Multiplier<F> mr(r);
+                for (int p = 0; p < a.nprod; p++) {
+                    Fe<F> lo[NFAC], hi[NFAC];
 #pragma unroll
-                for (int f = 0; f < NFAC; f++) {
-                    const void *src = prev ? (const void *)(prev + (size_t)(p * NFAC + f) * cl * esz) : a.tabs.in[p * NFAC + f];
-                    void *out = dst + (size_t)(p * NFAC + f) * ol * esz;
-                    Fe<F> a0 = fe_load<F>(src, tid), a1 = fe_load<F>(src, tid + q);
-                    Fe<F> b0 = fe_load<F>(src, tid + 2 * q), b1 = fe_load<F>(src, tid + 3 * q);
-                    lo[f] = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
-                    hi[f] = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
-                    fe_store<F>(out, tid, lo[f]);
-                    fe_store<F>(out, tid + q, hi[f]);
+                    for (int f = 0; f < NFAC; f++) {
+                        const void *src = prev ? (const void *)(prev + (size_t)(p * NFAC + f) * cl * esz) : a.tabs.in[p * NFAC + f];
+                        void *out = dst + (size_t)(p * NFAC + f) * ol * esz;
+                        Fe<F> a0 = fe_load<F>(src, tid), a1 = fe_load<F>(src, tid + q);
+                        Fe<F> b0 = fe_load<F>(src, tid + 2 * q), b1 = fe_load<F>(src, tid + 3 * q);
+                        lo[f] = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
+                        hi[f] = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
+                        fe_store<F>(out, tid, lo[f]);
+                        fe_store<F>(out, tid + q, hi[f]);
+                    }
+                    accumulate_terms<F, NFAC>(lo, hi, acc);
                 }
-                accumulate_terms<F, NFAC>(lo, hi, acc);
+            }
+        } else if constexpr (NFAC == 2) {
+            const unsigned qlog = 31u - (unsigned)__builtin_clz((unsigned)q);
+            const unsigned i = tid & ((unsigned)q - 1u), grp = tid >> qlog;      // pair index, product (split 1) or table (split 2)
+            const Multiplier<F> mr(r);
+            if (split == 1) {
+                if (grp < (unsigned)a.nprod) {
+                    Fe<F> lo[NFAC], hi[NFAC];
+#pragma unroll
+                    for (int f = 0; f < NFAC; f++) {
+                        const int k = (int)grp * NFAC + f;
+                        const void *src = prev ? (const void *)(prev + (size_t)k * cl * esz) : a.tabs.in[k];
+                        void *out = dst + (size_t)k * ol * esz;
+                        Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
+                        Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
+                        lo[f] = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
+                        hi[f] = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
+                        fe_store<F>(out, i, lo[f]);
+                        fe_store<F>(out, i + q, hi[f]);
+                    }
+                    accumulate_terms<F, NFAC>(lo, hi, acc);
+                }
+            } else {
+                __shared__ Fe<F> exch[2 * kTailSplit];           // (lo, hi) of table k at pair index i: exch[2 (k q + i) ..]
+                const bool act = grp < (unsigned)a.ntab;
+                Fe<F> lo = fe_zero<F>(), hi = fe_zero<F>();
+                if (act) {
+                    const void *src = prev ? (const void *)(prev + (size_t)grp * cl * esz) : a.tabs.in[grp];
+                    void *out = dst + (size_t)grp * ol * esz;
+                    Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
+                    Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
+                    lo = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
+                    hi = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
+                    fe_store<F>(out, i, lo);
+                    fe_store<F>(out, i + q, hi);
+                    exch[2 * (grp * (unsigned)q + i)] = lo;
+                    exch[2 * (grp * (unsigned)q + i) + 1] = hi;
+                }
+                __syncthreads();
+                if (act) {
+                    const unsigned other = grp ^ 1u;             // the other factor of the same product
+                    const Fe<F> lo2 = exch[2 * (other * (unsigned)q + i)], hi2 = exch[2 * (other * (unsigned)q + i) + 1];
+                    if ((grp & 1u) == 0) {                       // points 0 and 2: lo lo', (2 hi - lo)(2 hi' - lo')
+                        wide_add_fe<F>(acc[0], fe_mul<F>(lo, lo2));
+                        wide_add_fe<F>(acc[2], fe_mul<F>(fe_add<F>(hi, fe_sub<F>(hi, lo)), fe_add<F>(hi2, fe_sub<F>(hi2, lo2))));
+                    } else {                                     // point 1: hi hi'
+                        wide_add_fe<F>(acc[1], fe_mul<F>(hi, hi2));
+                    }
+                }
             }
         }
         Fe<F> tot;
