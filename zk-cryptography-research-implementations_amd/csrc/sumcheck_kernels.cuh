@@ -317,6 +317,42 @@ __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables 
     write_partials<F, NFAC>(acc, sh, partials);
 }
 
+// The same round for SHORT tables of products of two factors.  Below ~2^15 pair indices the launch above does not fill the
+// device and lasts as long as one lane's chain of products (14 for two products); here a wave takes ONE table for 64 consecutive
+// pair indices (2 fold products per lane), the factors of a product meet in LDS, and the even wave of a product evaluates the
+// points 0 and 2, the odd one the point 1: a chain of 4.  blockDim = 64 * ntab (ntab <= 8), grid = q / 64 = the number of partials.
+constexpr size_t kSplitRoundMaxQ = (size_t)1 << 15;
+template <class F>
+__global__ void __launch_bounds__(512) fold_round_evals_split_kernel(SumPolyTables tabs, size_t q, Fe<F> r, void *__restrict__ partials,
+                                                                     const void *__restrict__ rp, int skip1) {
+    __shared__ Fe<F> exch[2 * 64 * 8];
+    __shared__ Wide<F> sh[3 * 8];
+    const unsigned k = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;           // q is a multiple of 64
+    Wide<F> acc[3] = {wide_zero<F>(), wide_zero<F>(), wide_zero<F>()};
+    const Multiplier<F> mr(challenge_arg<F>(r, rp));
+    const void *src = tabs.in[k];
+    void *dst = tabs.out[k];
+    Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
+    Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
+    const Fe<F> lo = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
+    const Fe<F> hi = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
+    fe_store<F>(dst, i, lo);
+    fe_store<F>(dst, i + q, hi);
+    exch[2 * (k * 64 + lane)] = lo;
+    exch[2 * (k * 64 + lane) + 1] = hi;
+    __syncthreads();
+    const Fe<F> lo2 = exch[2 * ((k ^ 1u) * 64 + lane)], hi2 = exch[2 * ((k ^ 1u) * 64 + lane) + 1];
+    if ((k & 1u) == 0) {
+        wide_add_fe<F>(acc[0], fe_mul<F>(lo, lo2));
+        wide_add_fe<F>(acc[2], fe_mul<F>(fe_add<F>(hi, fe_sub<F>(hi, lo)), fe_add<F>(hi2, fe_sub<F>(hi2, lo2))));
+    } else if (!skip1) {
+        wide_add_fe<F>(acc[1], fe_mul<F>(hi, hi2));
+    }
+    Fe<F> tot;
+    if (block_reduce_wide<F, 3>(acc, sh, tot)) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
+}
+
 // element-wise reduce of a SumPolynomial to one table: out[i] = sum_p prod_f X[p][f][i]
 // (add_polynomials_element_wise sum_polynomial.rs:57-76 over multiply_polynomials_element_wise
 //  product_polynomial.rs:58-73)

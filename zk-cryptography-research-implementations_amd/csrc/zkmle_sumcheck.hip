@@ -272,8 +272,17 @@ template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, 
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
-template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t q, const Fe<F> &r, void *part, int grid,
-                                               const void *rp = nullptr, int skip1 = 0) {
+// `grid` = the number of partials written per evaluation point.  With `may_split` the caller lets short rounds of two-factor
+// products take the split kernel, which changes `grid` (sumcheck_kernels.cuh).
+template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t q, const Fe<F> &r, void *part, int &grid,
+                                               const void *rp = nullptr, int skip1 = 0, bool may_split = false) {
+    static const size_t split_max_q = [] { const char *e = getenv("ZK_SPLIT_ROUND_BITS"); int b = e ? atoi(e) : 0; return b >= 6 && b <= 24 ? (size_t)1 << b : kSplitRoundMaxQ; }();
+    if (may_split && nfac == 2 && nprod >= 2 && nprod <= 4 && q >= 64 && q <= split_max_q) {
+        grid = (int)(q / 64);
+        fold_round_evals_split_kernel<F><<<grid, 64 * 2 * nprod, 0, cur_stream()>>>(tabs, q, r, part, rp, skip1);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
     if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
     else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
     else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
@@ -365,7 +374,7 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
         // (dev_transcript.cuh kDerive1).  Below ~2^14 pair indices the helper wave's two products take longer than the
         // reduction they hide behind, so small rounds evaluate the point 1 directly (measured r1: 4 x 2^22 1.28 -> 1.23 ms).
         const int skip1 = q >= ((size_t)1 << 14) ? 1 : 0;
-        ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1)));
+        ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true)));
         ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, per * (round + 1), per * (round + 1) + npts, skip1, per));
         for (size_t k = 0; k < ntab; k++) tabs.in[k] = tabs.out[k];
         char *nx = other;
@@ -485,7 +494,7 @@ template <class F> struct RoundsImpl : RoundsBase {
             void *part;
             ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
             const int skip1 = q >= ((size_t)1 << 14) ? 1 : 0;
-            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1)));
+            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true)));
             skipped1 = skip1 != 0;                                       // e(1) = claim - e(0), after the all-reduce
             ZK_TRY(to_limbs(part, grid, limbs));
         } else {                                                         // 2 entries -> 1: nothing left to evaluate
