@@ -174,6 +174,79 @@ __device__ __forceinline__ G1XyzzU g1u_add(const G1XyzzU &a, const G1XyzzU &b) {
     return o;
 }
 
+// ---- one point operation by the four lanes of a quad ---------------------------------------------------------------------------
+// The late levels of the bucket reduction have a handful of additions each: a level lasts as long as ONE lane's chain of 14
+// products.  Here the four lanes of a DPP quad hold the same operands, each takes one of the (up to four) independent products
+// of a stage, and the results are broadcast inside the quad with quad_perm moves (VALU rate, no LDS): 4 product-times per
+// addition instead of 14, 3-4 per doubling instead of 10.  All four lanes return the same point.
+template <int J> __device__ __forceinline__ FqU quad_bcast(const FqU &v) {
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < UParams<Fq381>::L; i++)
+        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], J * 0x55, 0xf, 0xf, false);
+    return r;
+}
+__device__ __forceinline__ FqU quad_sel(unsigned q, const FqU &a0, const FqU &a1, const FqU &a2, const FqU &a3) {
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < UParams<Fq381>::L; i++) r.l[i] = q == 0 ? a0.l[i] : (q == 1 ? a1.l[i] : (q == 2 ? a2.l[i] : a3.l[i]));
+    return r;
+}
+__device__ __forceinline__ G1XyzzU g1u_dbl_quad(const G1XyzzU &a, unsigned q) {
+    using F = Fq381;
+    if (a.inf) return a;
+    const FqU u = uadd<F>(a.y, a.y);
+    // stage 1: V = U^2 | XX = X^2
+    FqU t = umul<F>(quad_sel(q, u, a.x, u, a.x), quad_sel(q, u, a.x, u, a.x));
+    const FqU v = quad_bcast<0>(t), xx = quad_bcast<1>(t);
+    const FqU m = uadd<F>(uadd<F>(xx, xx), xx);
+    // stage 2: W = U V | S = X V | MM = M^2 | ZZ3 = V ZZ
+    t = umul<F>(quad_sel(q, u, a.x, m, v), quad_sel(q, v, v, m, a.zz));
+    const FqU w = quad_bcast<0>(t), s = quad_bcast<1>(t), mm = quad_bcast<2>(t), zz3 = quad_bcast<3>(t);
+    const FqU x3u = usub<F>(mm, uadd<F>(s, s));
+    // stage 3: X3 renormalised (< 2 p: it is a subtrahend) | W Y | W ZZZ
+    t = umul<F>(quad_sel(q, x3u, w, w, w), quad_sel(q, fqu_one(), a.y, a.zzz, a.zzz));
+    const FqU x3 = quad_bcast<0>(t), wy = quad_bcast<1>(t), zzz3 = quad_bcast<2>(t);
+    // stage 4: M (S - X3)
+    const FqU y3a = umul<F>(m, usub<F>(s, x3));
+    G1XyzzU o;
+    o.x = x3;
+    o.y = usub<F>(y3a, wy);
+    o.zz = zz3;
+    o.zzz = zzz3;
+    o.inf = false;
+    return o;
+}
+__device__ __forceinline__ G1XyzzU g1u_add_quad(const G1XyzzU &a, const G1XyzzU &b, unsigned q) {
+    using F = Fq381;
+    if (a.inf) return b;
+    if (b.inf) return a;
+    // stage 1: U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1
+    FqU t = umul<F>(quad_sel(q, a.x, b.x, a.y, b.y), quad_sel(q, b.zz, a.zz, b.zzz, a.zzz));
+    const FqU u1 = quad_bcast<0>(t), u2 = quad_bcast<1>(t), s1 = quad_bcast<2>(t), s2 = quad_bcast<3>(t);
+    const FqU pn = usub<F>(u1, u2), rn = usub<F>(s1, s2);
+    // stage 2: PP = P'^2 | RR = R'^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2
+    t = umul<F>(quad_sel(q, pn, rn, a.zz, a.zzz), quad_sel(q, pn, rn, b.zz, b.zzz));
+    const FqU pp = quad_bcast<0>(t), rr = quad_bcast<1>(t), zz12 = quad_bcast<2>(t), zzz12 = quad_bcast<3>(t);
+    // stage 3: PPP' = P' PP | Q = U1 PP | ZZ3 = ZZ12 PP
+    t = umul<F>(quad_sel(q, pn, u1, zz12, zz12), pp);
+    const FqU pppn = quad_bcast<0>(t), qq = quad_bcast<1>(t), zz3 = quad_bcast<2>(t);
+    if (u_is_zero_mod_p<F>(zz3)) {                     // the same x coordinate (rare): every lane redoes it alone, exactly
+        if (fqu_is_zero(pn)) return fqu_is_zero(rn) ? g1u_dbl(a) : g1u_inf();
+    }
+    const FqU x3 = usub<F>(uadd<F>(rr, pppn), uadd<F>(qq, qq));
+    // stage 4: R' (X3 - Q) | S1 PPP' | ZZZ12 PPP'
+    t = umul<F>(quad_sel(q, rn, s1, zzz12, zzz12), quad_sel(q, usub<F>(x3, qq), pppn, pppn, pppn));
+    const FqU y3a = quad_bcast<0>(t), y3b = quad_bcast<1>(t), z3 = quad_bcast<2>(t);
+    G1XyzzU o;
+    o.x = x3;
+    o.y = uadd<F>(y3a, y3b);
+    o.zz = zz3;
+    o.zzz = usub<F>(u_zero<F>(), z3);
+    o.inf = false;
+    return o;
+}
+
 // internal accumulator -> stored XYZZ (canonical 32-bit Montgomery limbs)
 __device__ __forceinline__ G1Xyzz g1u_to_std(const G1XyzzU &a) {
     using F = Fq381;

@@ -48,8 +48,12 @@ __global__ void __launch_bounds__(256) msm_bucket_combine_kernel(const void *__r
 // The two updates of a pair are independent (A' writes the low half of A, R' reads the high half of A), so they run in
 // different lanes: the first nwin * half lanes take A', the next nwin * half take R' -- the level's critical path is
 // add, double, add instead of those plus one more add (the late levels are pure latency).
+// QUAD: four lanes per work item (g1u_add_quad / g1u_dbl_quad) for the short, latency-bound levels.
+template <bool QUAD>
 __global__ void __launch_bounds__(256) msm_reduce_level_kernel(void *__restrict__ A, void *__restrict__ R, unsigned nwin, unsigned c, size_t half) {
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned q = QUAD ? (unsigned)(id & 3u) : 0u;
+    if (QUAD) id >>= 2;
     const size_t work = (size_t)nwin * half;
     if (id >= 2 * work) return;
     const bool second = id >= work;
@@ -58,10 +62,13 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(void *__restrict_
     size_t base = w << (c - 1);
     G1XyzzU ahi = g1u_load_xyzz(A, base + b + half);
     if (!second) {
-        g1u_store_xyzz(A, base + b, g1u_add(g1u_load_xyzz(A, base + b), ahi));
+        G1XyzzU alo = g1u_load_xyzz(A, base + b);
+        G1XyzzU r = QUAD ? g1u_add_quad(alo, ahi, q) : g1u_add(alo, ahi);
+        if (q == 0) g1u_store_xyzz(A, base + b, r);
     } else {
         G1XyzzU rlo = g1u_load_xyzz(R, base + b), rhi = g1u_load_xyzz(R, base + b + half);
-        g1u_store_xyzz(R, base + b, g1u_add(ahi, g1u_dbl(g1u_add(rlo, rhi))));
+        G1XyzzU r = QUAD ? g1u_add_quad(ahi, g1u_dbl_quad(g1u_add_quad(rlo, rhi, q), q), q) : g1u_add(ahi, g1u_dbl(g1u_add(rlo, rhi)));
+        if (q == 0) g1u_store_xyzz(R, base + b, r);
     }
 }
 
@@ -71,22 +78,29 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(void *__restrict_
 // with the plain sums C[l] = sum_h A[h][l] and D[h] = sum_l A[h][l].  The plain sums are halving trees of ONE addition per
 // level (A reduces over h in place, a copy of it reduces over l), and only the two short arrays C and D go through the
 // 3-operation weighted levels: log2(nb) levels of (add, double, add) become log2(H) plain + log2(L) weighted levels.
+template <bool QUAD>
 __global__ void __launch_bounds__(256) msm_plain_level_kernel(void *__restrict__ A, void *__restrict__ B, unsigned nwin, unsigned cm1, unsigned k,
                                                               size_t hh, size_t lh) {
     // role 1: A[w][h][l] += A[w][h + hh][l], h < hh (all l);  role 2: B[w][h][l] += B[w][h][l + lh], l < lh (all h)
     const size_t L = (size_t)1 << k, H = (size_t)1 << (cm1 - k);
     const size_t work1 = (size_t)nwin * hh * L, work2 = (size_t)nwin * H * lh;
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned q = QUAD ? (unsigned)(id & 3u) : 0u;
+    if (QUAD) id >>= 2;
     if (id < work1) {
         size_t w = id / (hh * L), r = id % (hh * L);
         size_t base = (w << cm1) + r;
-        g1u_store_xyzz(A, base, g1u_add(g1u_load_xyzz(A, base), g1u_load_xyzz(A, base + hh * L)));
+        G1XyzzU x = g1u_load_xyzz(A, base), y = g1u_load_xyzz(A, base + hh * L);
+        G1XyzzU s = QUAD ? g1u_add_quad(x, y, q) : g1u_add(x, y);
+        if (q == 0) g1u_store_xyzz(A, base, s);
     } else if (id < work1 + work2) {
         id -= work1;
         size_t w = id / (H * lh), r = id % (H * lh);
         size_t h = r / lh, l = r % lh;
         size_t base = (w << cm1) + h * L + l;
-        g1u_store_xyzz(B, base, g1u_add(g1u_load_xyzz(B, base), g1u_load_xyzz(B, base + lh)));
+        G1XyzzU x = g1u_load_xyzz(B, base), y = g1u_load_xyzz(B, base + lh);
+        G1XyzzU s = QUAD ? g1u_add_quad(x, y, q) : g1u_add(x, y);
+        if (q == 0) g1u_store_xyzz(B, base, s);
     }
 }
 // compact the two short arrays, zero-padded to M = 2^mbits entries: X[0][w][l] = C[l] = A[w][l],  X[1][w][h] = D[h] = B[w][h L]
@@ -136,10 +150,13 @@ int launch_msm_window_sums(const void *A, const void *R, unsigned nwin, unsigned
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
+// levels with at most this many additions use four lanes per addition (measured: a level of <= ~2^13 additions is latency)
+constexpr size_t kQuadLevelWork = (size_t)1 << 13;
 int launch_msm_plain_level(void *A, void *B, unsigned nwin, unsigned cm1, unsigned k, size_t hh, size_t lh, hipStream_t s) {
     size_t work = (size_t)nwin * ((hh << k) + (((size_t)1 << (cm1 - k)) * lh));
     if (work == 0) return ZK_OK;
-    msm_plain_level_kernel<<<(unsigned)((work + 255) / 256), 256, 0, s>>>(A, B, nwin, cm1, k, hh, lh);
+    if (work <= kQuadLevelWork) msm_plain_level_kernel<true><<<(unsigned)((4 * work + 255) / 256), 256, 0, s>>>(A, B, nwin, cm1, k, hh, lh);
+    else msm_plain_level_kernel<false><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(A, B, nwin, cm1, k, hh, lh);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -156,7 +173,8 @@ int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsign
 }
 int launch_msm_reduce_level(void *A, void *R, unsigned nwin, unsigned c, size_t half, hipStream_t s) {
     size_t work = 2 * (size_t)nwin * half;
-    msm_reduce_level_kernel<<<(unsigned)((work + 255) / 256), 256, 0, s>>>(A, R, nwin, c, half);
+    if (work <= kQuadLevelWork) msm_reduce_level_kernel<true><<<(unsigned)((4 * work + 255) / 256), 256, 0, s>>>(A, R, nwin, c, half);
+    else msm_reduce_level_kernel<false><<<(unsigned)((work + 255) / 256), 256, 0, s>>>(A, R, nwin, c, half);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
