@@ -115,15 +115,42 @@ __global__ void msm_gather_cd_kernel(const void *__restrict__ A, const void *__r
     else if (i < H) v = g1u_load_xyzz(B, (w << cm1) + i * L);
     g1u_store_xyzz(X, id, v);
 }
-// out[3 w .. 3 w + 2] = sum_l l C[l], sum_l C[l], sum_h h D[h]  (R_l[0], A_l[0], R_h[0] of the weighted reductions)
+// out[3 w .. 3 w + 2] = sum_l l C[l], sum_l C[l], sum_h h D[h]  (R_l[0], A_l[0], R_h[0] of the weighted reductions).
+// The results leave the internal form here (stored XYZZ, canonical limbs) for the host's window combination: one lane per
+// coordinate (12 per window), one product each.
 __global__ void msm_two_stage_out_kernel(const void *__restrict__ X, const void *__restrict__ Y, unsigned nwin, unsigned mbits, void *__restrict__ out) {
-    unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwin) return;
+    unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 12u * nwin) return;
+    const unsigned w = id / 12u, pt = (id % 12u) / 4u, co = id % 4u;
     const size_t M = (size_t)1 << mbits;
-    // the results leave the internal form here (stored XYZZ, canonical limbs) for the host's window combination
-    g1_store_xyzz(out, 3 * (size_t)w, g1u_to_std(g1u_load_xyzz(Y, (size_t)w * M)));
-    g1_store_xyzz(out, 3 * (size_t)w + 1, g1u_to_std(g1u_load_xyzz(X, (size_t)w * M)));
-    g1_store_xyzz(out, 3 * (size_t)w + 2, g1u_to_std(g1u_load_xyzz(Y, ((size_t)nwin + w) * M)));
+    const void *src = pt == 1 ? X : Y;
+    const size_t idx = pt == 2 ? ((size_t)nwin + w) * M : (size_t)w * M;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(src) + idx * (4 * kUWords);
+    const bool inf = u_is_exact_zero<Fq381>(fqu_load(p + 2 * kUWords));
+    fe_store<Fq>(out, 4 * (3 * (size_t)w + pt) + co, inf ? fe_zero<Fq>() : u_to_std<Fq381>(fqu_load(p + co * kUWords)));
+}
+// every level of the weighted reduction of the short arrays (X: values, Y: running weighted sums, M = 2^mbits entries each) in
+// ONE launch: a workgroup per array, a quad per item, __syncthreads between the levels (level after level as separate launches
+// cost ~8 us of launch, load and store latency each, on top of the arithmetic).  Same operations as msm_reduce_level_kernel.
+__global__ void __launch_bounds__(512) msm_weighted_tail_kernel(void *__restrict__ X, void *__restrict__ Y, unsigned mbits) {
+    const size_t base = (size_t)blockIdx.x << mbits;
+    const unsigned quad = threadIdx.x >> 2, q = threadIdx.x & 3u, nquads = blockDim.x >> 2;
+    for (size_t half = (size_t)1 << (mbits - 1); half >= 1; half >>= 1) {
+        for (size_t item = quad; item < 2 * half; item += nquads) {
+            const bool second = item >= half;
+            const size_t b = second ? item - half : item;
+            G1XyzzU ahi = g1u_load_xyzz(X, base + b + half);
+            if (!second) {
+                G1XyzzU r = g1u_add_quad(g1u_load_xyzz(X, base + b), ahi, q);
+                if (q == 0) g1u_store_xyzz(X, base + b, r);
+            } else {
+                G1XyzzU rlo = g1u_load_xyzz(Y, base + b), rhi = g1u_load_xyzz(Y, base + b + half);
+                G1XyzzU r = g1u_add_quad(ahi, g1u_dbl_quad(g1u_add_quad(rlo, rhi, q), q), q);
+                if (q == 0) g1u_store_xyzz(Y, base + b, r);
+            }
+        }
+        __syncthreads();                                     // workgroup-scope: the level's stores are visible to the next level
+    }
 }
 
 __global__ void msm_window_sums_kernel(const void *__restrict__ A, const void *__restrict__ R, unsigned nwin, unsigned c, void *__restrict__ out) {
@@ -167,7 +194,12 @@ int launch_msm_gather_cd(const void *A, const void *B, unsigned nwin, unsigned c
     return ZK_OK;
 }
 int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsigned mbits, void *out, hipStream_t s) {
-    msm_two_stage_out_kernel<<<(nwin + 63) / 64, 64, 0, s>>>(X, Y, nwin, mbits, out);
+    msm_two_stage_out_kernel<<<(12 * nwin + 63) / 64, 64, 0, s>>>(X, Y, nwin, mbits, out);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int launch_msm_weighted_tail(void *X, void *Y, unsigned narrays, unsigned mbits, hipStream_t s) {
+    msm_weighted_tail_kernel<<<narrays, 512, 0, s>>>(X, Y, mbits);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }

@@ -249,10 +249,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         ZK_TRY(out3.alloc(3 * (size_t)nwin * sizeof(G1Xyzz)));
         ZK_HIP(hipMemsetAsync(Y.p, 0, small_bytes, cur_stream()));
         ZK_TRY(launch_msm_gather_cd(A.p, R.p, nwin, cm1, k, mbits, X.p, cur_stream()));
-        for (size_t half = (size_t)1 << (mbits - 1); half >= 1; half >>= 1) {   // 2 nwin problems of 2^mbits entries, 0-based weights
-            ZK_TRY(launch_msm_reduce_level(X.p, Y.p, 2 * nwin, mbits + 1, half, cur_stream()));
-            if (half == 1) break;
-        }
+        ZK_TRY(launch_msm_weighted_tail(X.p, Y.p, 2 * nwin, mbits, cur_stream()));   // 2 nwin problems of 2^mbits entries, 0-based weights
         ZK_TRY(launch_msm_two_stage_out(X.p, Y.p, nwin, mbits, out3.p, cur_stream()));
         std::vector<G1Xyzz> o(3 * (size_t)nwin);
         ZK_HIP(hipMemcpyAsync(o.data(), out3.p, o.size() * sizeof(G1Xyzz), hipMemcpyDeviceToHost, cur_stream()));
