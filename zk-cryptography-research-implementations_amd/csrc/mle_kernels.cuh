@@ -288,11 +288,13 @@ inline int grid_for(size_t work, int cap = kMaxBlocks) {
 }
 // grid cap of the reduction kernels (one partial per block).  Measured r1, 2^24 fused round (fold_half_sums_kernel): with
 // modular sums 2048 -> 188 us, 4096 -> 158, 16384 -> 170; with the lazy sums 2048 / 4096 / 8192 / 16384 -> 143 / 144 / 139 / 142
-// (noise), while the one-workgroup finish kernel grows with the partial count (23 -> 34 us): 4096.  ZK_REDUCE_BLOCKS overrides.
+// (noise), while the one-workgroup finish kernel grows with the partial count (23 -> 34 us).  Whole provers, end of r1 (768 / 1536 /
+// 3072 / 4096 / 6144 blocks): 2^24 basic rounds 0.871 / 0.878 / 0.883 / 0.896 / 0.892 ms, 4 x 2^22 GKR 1.072 / 1.071 / 1.078 / 1.093 / 1.117:
+// 1536.  ZK_REDUCE_BLOCKS overrides.
 inline int reduce_block_cap() {
     static const int v = [] {
         const char *e = getenv("ZK_REDUCE_BLOCKS");
-        int k = e ? atoi(e) : 4096;
+        int k = e ? atoi(e) : 1536;
         return k < 64 ? 64 : (k > kMaxReduceBlocks ? kMaxReduceBlocks : k);
     }();
     return v;
