@@ -3,9 +3,9 @@
 //
 // The reference doubles the table once per variable.  Level by level that is one launch per variable, and the
 // first dozen launches are latency only (measured: 22 launches x ~7.6 us for a 2^22 table).  Here the table is the
-// outer product of the tables of its high and low variable halves, recursively, so a 2^22 table is 4 tiny direct
-// kernels (<= 6 variables: the product is taken directly, 6 multiplications per entry) and 3 outer-product
-// kernels, the last of which does all the real work: one multiplication and one 32-byte store per entry.
+// outer product of the tables of its high and low variable halves: a 2^22 table is ONE small launch that builds both
+// 11-variable halves (each itself the outer product, in LDS, of two <= 6-variable tables) and ONE outer-product kernel that
+// does all the real work: one multiplication and one 32-byte store per entry.
 // Products of the same factors in another order are the same field element: the table is unchanged bit for bit.
 #pragma once
 #include <vector>
@@ -17,24 +17,6 @@ namespace zk {
 
 constexpr int kEqDirectBits = 6;
 
-template <class F> struct EqPoint {
-    Fe<F> tau[kEqDirectBits];
-};
-
-// out[idx] = prod_i (bit ? tau_i : 1 - tau_i) over nbits <= kEqDirectBits variables, MSB first
-template <class F> __global__ void eq_direct_kernel(EqPoint<F> pt, int nbits, void *__restrict__ out) {
-    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (1u << nbits)) return;
-    Fe<F> acc = fe_one<F>();
-#pragma unroll 1
-    for (int i = 0; i < nbits; i++) {
-        const Fe<F> t = pt.tau[i];
-        const bool bit = (idx >> (nbits - 1 - i)) & 1u;
-        acc = fe_mul<F>(acc, bit ? t : fe_sub<F>(fe_one<F>(), t));
-    }
-    fe_store<F>(out, idx, acc);
-}
-
 // out[i] = hi[i >> lbits] * lo[i & (2^lbits - 1)]
 template <class F> __global__ void eq_outer_kernel(const void *__restrict__ hi, const void *__restrict__ lo, unsigned lbits, size_t n,
                                                    void *__restrict__ out) {
@@ -43,10 +25,45 @@ template <class F> __global__ void eq_outer_kernel(const void *__restrict__ hi, 
         fe_store<F>(out, i, fe_mul<F>(fe_load<F>(hi, i >> lbits), fe_load<F>(lo, i & mask)));
 }
 
+// Tables of up to 2 kEqDirectBits = 12 variables in ONE launch by one workgroup: the two <= 6-variable half tables in LDS (a chain of
+// <= 6 products), then one product per entry.  blockIdx.x selects one of up to two independent tables (the halves of a larger one).
+constexpr int kEqSmallBits = 2 * kEqDirectBits;
+template <class F> struct EqSmallArgs {
+    Fe<F> tau[2][kEqSmallBits];
+    int nbits[2];
+    void *out[2];
+};
+template <class F> __global__ void __launch_bounds__(1024) eq_small_kernel(EqSmallArgs<F> a) {
+    __shared__ Fe<F> th[1 << kEqDirectBits], tl[1 << kEqDirectBits];
+    const int which = blockIdx.x, nbits = a.nbits[which];
+    const int hbits = nbits / 2, lbits = nbits - hbits;        // variables 0..hbits-1 are the high index bits (MSB first)
+    const unsigned tid = threadIdx.x;
+    if (tid < 128) {
+        const bool low = tid >= 64;
+        const unsigned idx = tid & 63u;
+        const int nb = low ? lbits : hbits, off = low ? hbits : 0;
+        if (idx < (1u << nb)) {
+            Fe<F> acc = fe_one<F>();
+#pragma unroll 1
+            for (int i = 0; i < nb; i++) {
+                const Fe<F> t = a.tau[which][off + i];
+                const bool bit = (idx >> (nb - 1 - i)) & 1u;
+                acc = fe_mul<F>(acc, bit ? t : fe_sub<F>(fe_one<F>(), t));
+            }
+            (low ? tl : th)[idx] = acc;
+        }
+    }
+    __syncthreads();
+    const unsigned n = 1u << nbits, mask = (1u << lbits) - 1u;
+    for (unsigned e = tid; e < n; e += blockDim.x) fe_store<F>(a.out[which], e, fe_mul<F>(th[e >> lbits], tl[e & mask]));
+}
+
 // Enqueue the construction of the 2^nbits-entry table of `point` (nbits elements, u64 limbs) into `out` (device).
 // Temporaries come from the caching pool and are returned to it when the caller calls release() -- after the
-// stream has been synchronised or further work on the same stream has been enqueued (the pool is stream-ordered by
-// construction: every kernel of this library runs on the null stream).
+// stream has been synchronised or further work on the same stream has been enqueued (the pool is stream-ordered).
+// A table of <= 12 variables is one launch; one of <= 24 variables is two: both halves by eq_small_kernel, then the outer
+// product (r1: the recursion down to 6-variable direct kernels took 7 dependent launches per 22-variable table, ~45 us of
+// launch latency before the one kernel that does the work).
 template <class F> struct EqBuilder {
     std::vector<void *> temps;
     ~EqBuilder() { release(); }
@@ -54,14 +71,20 @@ template <class F> struct EqBuilder {
         for (void *p : temps) pool_free(p);
         temps.clear();
     }
+    static void load_taus(Fe<F> *dst, const uint64_t *point, uint32_t nbits) {
+        for (int i = 0; i < kEqSmallBits; i++) {
+            if ((uint32_t)i < nbits) memcpy(dst[i].l, point + (size_t)i * (F::N / 2), 4 * F::N);
+            else dst[i] = fe_zero<F>();
+        }
+    }
     int build(const uint64_t *point, uint32_t nbits, void *out) {
-        if (nbits <= (uint32_t)kEqDirectBits) {
-            EqPoint<F> pt;
-            for (int i = 0; i < kEqDirectBits; i++) {
-                if ((uint32_t)i < nbits) memcpy(pt.tau[i].l, point + (size_t)i * (F::N / 2), 4 * F::N);
-                else pt.tau[i] = fe_zero<F>();
-            }
-            eq_direct_kernel<F><<<1, 64, 0, cur_stream()>>>(pt, (int)nbits, out);
+        if (nbits <= (uint32_t)kEqSmallBits) {
+            EqSmallArgs<F> a;
+            load_taus(a.tau[0], point, nbits);
+            load_taus(a.tau[1], point, 0);
+            a.nbits[0] = (int)nbits; a.nbits[1] = 0;
+            a.out[0] = out; a.out[1] = nullptr;
+            eq_small_kernel<F><<<1, 1024, 0, cur_stream()>>>(a);
             ZK_HIP(hipGetLastError());
             return ZK_OK;
         }
@@ -71,8 +94,18 @@ template <class F> struct EqBuilder {
         temps.push_back(hi);
         ZK_TRY(pool_alloc(((size_t)1 << lbits) * 4 * F::N, &lo));
         temps.push_back(lo);
-        ZK_TRY(build(point, hbits, hi));
-        ZK_TRY(build(point + (size_t)hbits * (F::N / 2), lbits, lo));
+        if (lbits <= (uint32_t)kEqSmallBits) {                         // both halves in one launch
+            EqSmallArgs<F> a;
+            load_taus(a.tau[0], point, hbits);
+            load_taus(a.tau[1], point + (size_t)hbits * (F::N / 2), lbits);
+            a.nbits[0] = (int)hbits; a.nbits[1] = (int)lbits;
+            a.out[0] = hi; a.out[1] = lo;
+            eq_small_kernel<F><<<2, 1024, 0, cur_stream()>>>(a);
+            ZK_HIP(hipGetLastError());
+        } else {
+            ZK_TRY(build(point, hbits, hi));
+            ZK_TRY(build(point + (size_t)hbits * (F::N / 2), lbits, lo));
+        }
         const size_t n = (size_t)1 << nbits;
         eq_outer_kernel<F><<<grid_for(n), kBlock, 0, cur_stream()>>>(hi, lo, lbits, n, out);
         ZK_HIP(hipGetLastError());
