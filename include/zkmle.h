@@ -42,7 +42,8 @@ typedef enum {
     ZK_E_NOMEM = -8,
     ZK_E_NO_DEVICE = -9,    /* no usable HIP device: the product path has no CPU fallback */
     ZK_E_HIP = -10,         /* a HIP runtime call failed; see zk_last_error */
-    ZK_E_NOT_INIT = -11     /* "Can't prove without init" prover.rs:36 */
+    ZK_E_NOT_INIT = -11,    /* "Can't prove without init" prover.rs:36 */
+    ZK_E_COMM = -12         /* an RCCL call or a caller-supplied exchange callback failed; see zk_last_error */
 } zk_status;
 
 const char *zk_status_message(int status);
@@ -79,6 +80,9 @@ int zk_table_wrap(int field, void *device_ptr, size_t len, zk_table **out); /* n
 int zk_table_clone(const zk_table *t, zk_table **out);
 /* synthetic benchmark data: element i = SplitMix64-derived 4 (6) words reduced mod p */
 int zk_table_fill_random(zk_table *t, uint64_t seed);
+/* local entry j <- element (first + j * stride) of the stream `seed`: rank g of G generates its low-bit shard of a global
+ * table with (first, stride) = (g, G), its contiguous slice of an MSM's scalars with (g * n / G, 1) */
+int zk_table_fill_random_strided(zk_table *t, uint64_t seed, size_t first, size_t stride);
 /* host mirror of the generator (same bytes), for parity tests */
 int zk_host_fill_random(int field, uint64_t seed, size_t first, size_t count, uint64_t *out);
 
@@ -132,6 +136,10 @@ int zk_transcript_append(zk_transcript *t, const uint8_t *data, size_t n);      
 int zk_transcript_sample(zk_transcript *t, uint8_t out32[32]);                     /* sample_random_challenge :29 */
 int zk_transcript_challenge(zk_transcript *t, int field, uint64_t *out);           /* random_challenge_as_field_element :38 */
 int zk_keccak256(const uint8_t *data, size_t n, uint8_t out32[32]);
+/* the running sponge as 25 Keccak lanes + the fill of the open block: what one rank hands to the others after absorbing
+ * input only it has seen (the whole-table absorb of a sharded Prover::prove) */
+int zk_transcript_export_state(const zk_transcript *t, uint64_t lanes25[25], uint32_t *fill);
+int zk_transcript_import_state(zk_transcript *t, const uint64_t lanes25[25], uint32_t fill);
 
 /* ---- univariate helpers (host; polynomials/src/univariate/dense_univariate.rs) ------------------ */
 int zk_uni_evaluate(int field, const uint64_t *coeffs, size_t n, const uint64_t *x, uint64_t *out);        /* :57 */
@@ -360,6 +368,63 @@ int zk_gkr_sparse_wiring_eval(int field, const zk_gate *layer_gates, size_t ngat
 /* layer-by-layer evaluation of a sparse circuit on the GPU; evals = layer 0 .. inputs concatenated */
 int zk_sparse_circuit_evaluate(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers,
                                const uint32_t *out_bits, const uint64_t *inputs, size_t ninputs, uint64_t *evals);
+
+/* ---- multi-GPU provers: one process per GPU, RCCL over xGMI -------------------------------------
+ * A zk_comm is this rank's end of the node's communicator.  zk_comm_init_rccl creates an RCCL communicator on the calling
+ * thread's device (ncclCommInitRank; librccl.so.1 is opened at first use): rank 0 calls zk_comm_unique_id and ships the 128
+ * bytes to the other ranks out of band (file, MPI, torch.distributed store ...).  Every collective of the provers below is
+ * enqueued on the calling thread's current stream between the kernels it separates -- the device never waits for the host
+ * inside a sumcheck.  zk_comm_from_host_ops is the same interface over caller-supplied HOST-memory exchange callbacks (the
+ * library stages device <-> pinned host and synchronises around each call): for hosts that own another transport, and for
+ * the multi-rank tests on one GPU (RCCL refuses two ranks on one device).
+ * The tables of the reference's provers shard by the LOW index bits: rank g of G = 2^k holds the entries i == g (mod G) as a
+ * contiguous local table (local index i >> k), so that every round that folds variable 0 (prover.rs:62,
+ * sumcheck_gkr_protocol.rs:57) is local; MSM terms shard by contiguous slices. */
+typedef struct zk_comm zk_comm;
+typedef struct {
+    void *ctx;
+    /* in-place element-wise sum over the ranks of `count` int64 words */
+    int (*all_reduce_sum_i64)(void *ctx, int64_t *host_buf, size_t count);
+    /* recv = send buffers of all ranks in rank order (bytes each) */
+    int (*all_gather)(void *ctx, const void *host_send, void *host_recv, size_t bytes);
+    /* root's recv = send buffers of all ranks in rank order; recv is NULL on the other ranks */
+    int (*gather)(void *ctx, const void *host_send, void *host_recv, size_t bytes, int root);
+    int (*broadcast)(void *ctx, void *host_buf, size_t bytes, int root);
+} zk_comm_host_ops;                                               /* every callback returns 0 on success */
+int zk_comm_unique_id(uint8_t out128[128]);                       /* ncclGetUniqueId */
+int zk_comm_init_rccl(const uint8_t id128[128], int nranks, int rank, zk_comm **out);
+int zk_comm_from_host_ops(const zk_comm_host_ops *ops, int nranks, int rank, zk_comm **out);
+int zk_comm_free(zk_comm *c);
+int zk_comm_rank(const zk_comm *c);
+int zk_comm_size(const zk_comm *c);
+const char *zk_comm_backend(const zk_comm *c);                    /* "rccl" or "host-ops" */
+/* payload bytes this rank has received through the communicator so far (all-reduce: the buffer; all-gather / gather at the
+ * root: the other ranks' parts; broadcast: the buffer on non-root ranks) and the number of collectives issued */
+int zk_comm_stats(const zk_comm *c, uint64_t *bytes_received, uint64_t *collectives);
+/* primitives, on device buffers, enqueued on the current stream (what the provers below are made of) */
+int zk_comm_all_reduce_sum_i64(zk_comm *c, void *dev_buf, size_t count);
+int zk_comm_all_gather(zk_comm *c, const void *dev_send, void *dev_recv, size_t bytes);
+int zk_comm_broadcast(zk_comm *c, void *dev_buf, size_t bytes, int root);
+
+/* Prover::prove (prover.rs:35-71) of the global table whose low-bit shard is `shard` (local length 2^m, global 2^(m+k)).
+ * Same proof bytes on every rank as zk_sumcheck_basic_prove on the interleaved table.  Per local round: one fused kernel,
+ * ONE all-reduce of 18 int64 words, the transcript step on every rank's device.  absorb_table != 0 hashes the whole table
+ * first (:38-39): the ranks stream their canonical bytes to rank 0 in chunks (gather), rank 0 absorbs them in global index
+ * order and broadcasts the 208-byte sponge (25 lanes + fill) -- non-root ranks receive 208 bytes for the absorb. */
+int zk_sharded_sumcheck_basic_prove(zk_comm *c, const zk_table *shard, int absorb_table, uint64_t *claimed_sum,
+                                    uint64_t *round_polys /* (m + k) x 2 */, uint64_t *challenges /* m + k, may be NULL */);
+/* sumcheck_gkr_protocol::prove (:24-67) on low-bit shards of the nprod x nfac tables; `t` must hold the same state on every
+ * rank and is advanced identically.  final_values (nprod * nfac elements, may be NULL) = the fully folded tables. */
+int zk_sharded_sumcheck_gkr_prove(zk_comm *c, const zk_table *const *shards, size_t nprod, size_t nfac,
+                                  const uint64_t *claimed_sum, zk_transcript *t, uint64_t *round_coeffs, uint64_t *challenges,
+                                  uint64_t *final_values);
+/* MultilinearPolynomial::evaluate (evaluation_form.rs:21-33) of the sharded table at nvalues = m + k points: m local fold
+ * rounds, one all-gather of G elements, k replicated rounds */
+int zk_sharded_mle_evaluate(zk_comm *c, const zk_table *shard, const uint64_t *values, size_t nvalues, uint64_t *out);
+/* commit_to_polynomial (multilinear_kzg.rs:37-42) with the terms sliced over the ranks: one Pippenger per rank, one
+ * all-gather of G affine points (96 B each), G - 1 additions.  Same point on every rank. */
+int zk_sharded_msm_g1(zk_comm *c, const zk_table *scalars_slice, const zk_g1_bases *bases_slice, int window_bits,
+                      uint64_t *out12, zk_msm_stats *stats /* this rank's local MSM, may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -412,3 +412,75 @@ double orc_bench_commit_naive(const uint64_t *values, size_t len, const uint64_t
     orc_kzg_commit(values, len, g1_points, len, out);
     return now_s() - t0;
 }
+
+/* ---- best-effort CPU baseline for the MSM: the bucket method on all host cores -------------
+ * NOT a restatement of reference code (the reference has no MSM routine, multilinear_kzg.rs:37-42 is a naive sum); it computes
+ * the same group element as orc_kzg_commit (tests/test_oracle_kzg.py) and exists to be timed beside the GPU Pippenger.
+ * Unsigned c-bit windows; work items = (window, slice of the terms), each with its own 2^c - 1 buckets and a running-sum
+ * reduction; OpenMP over the items; per-window sums are combined by c doublings each, most significant window first. */
+static unsigned window_digit(const uint64_t *k, int w, int c) {
+    int bit = w * c, limb = bit / 64, off = bit % 64;
+    uint64_t v = k[limb] >> off;
+    if (off + c > 64 && limb + 1 < 4) v |= k[limb + 1] << (64 - off);
+    return (unsigned)(v & (((uint64_t)1 << c) - 1));
+}
+int orc_msm_pippenger(const uint64_t *values, size_t len, const uint64_t *g1_points, int c, int slices, uint64_t *out12, int *threads_used) {
+    if (c < 1 || c > 16 || slices < 1 || len == 0) return ORC_E_ARG;
+    const int W = (255 + c - 1) / c;
+    const size_t nb = ((size_t)1 << c) - 1;
+    uint64_t *canon = (uint64_t *)malloc(32 * len);
+    jac *partial = (jac *)malloc(sizeof(jac) * (size_t)W * (size_t)slices);
+    if (!canon || !partial) { free(canon); free(partial); return ORC_E_ARG; }
+    for (size_t i = 0; i < len; i++) {
+        fe s;
+        fe_load(FR(), &s, values + 4 * i);
+        fe_to_canonical(FR(), canon + 4 * i, &s);                 /* into_bigint()  multilinear_kzg.rs:41 */
+    }
+    int used = 1;
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#endif
+        jac *buckets = (jac *)malloc(sizeof(jac) * nb);
+#pragma omp for schedule(dynamic, 1)
+        for (int item = 0; item < W * slices; item++) {
+            const int w = item / slices, sl = item % slices;
+            const size_t lo = len * (size_t)sl / (size_t)slices, hi = len * (size_t)(sl + 1) / (size_t)slices;
+            for (size_t b = 0; b < nb; b++) { jac_inf(&buckets[b]); fe_zero(&buckets[b].z); }
+            for (size_t i = lo; i < hi; i++) {
+                unsigned dgt = window_digit(canon + 4 * i, w, c);
+                if (!dgt) continue;
+                jac p;
+                jac_from_affine(&p, g1_points + 12 * i);
+                jac_add(&buckets[dgt - 1], &buckets[dgt - 1], &p);
+            }
+            jac run, sum;                                          /* sum_b (b + 1) bucket[b] by the running sum */
+            jac_inf(&run); fe_zero(&run.z);
+            jac_inf(&sum); fe_zero(&sum.z);
+            for (size_t b = nb; b-- > 0;) {
+                jac_add(&run, &run, &buckets[b]);
+                jac_add(&sum, &sum, &run);
+            }
+            partial[item] = sum;
+        }
+        free(buckets);
+    }
+    jac acc;
+    jac_inf(&acc); fe_zero(&acc.z);
+    for (int w = W - 1; w >= 0; w--) {
+        for (int k = 0; k < c; k++) jac_double(&acc, &acc);
+        for (int sl = 0; sl < slices; sl++) jac_add(&acc, &acc, &partial[(size_t)w * slices + sl]);
+    }
+    jac_to_affine(out12, &acc);
+    free(canon);
+    free(partial);
+    if (threads_used) *threads_used = used;
+    return ORC_OK;
+}
+double orc_bench_pippenger_mt(const uint64_t *values, size_t len, const uint64_t *g1_points, int c, int slices, uint64_t *out12, int *threads_used) {
+    double t0 = now_s();
+    if (orc_msm_pippenger(values, len, g1_points, c, slices, out12, threads_used) != ORC_OK) return -1.0;
+    return now_s() - t0;
+}

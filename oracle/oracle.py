@@ -47,6 +47,7 @@ def lib():
         _lib.orc_transcript_new.restype = C.c_void_p
         _lib.orc_bench_fold.restype = C.c_double
         _lib.orc_bench_commit_naive.restype = C.c_double
+        _lib.orc_bench_pippenger_mt.restype = C.c_double
         _lib.orc_bench_fold_mt.restype = C.c_double
         for n in ("orc_num_layer_variables", "orc_wiring_index", "orc_circuit_eval_size", "orc_gkr_rounds"):
             getattr(_lib, n).restype = C.c_size_t
@@ -557,3 +558,33 @@ def bench_commit_naive(values, points):
     v = _arr(FR381, values)
     pts = np.ascontiguousarray(points, np.uint64).reshape(-1, 12)
     return lib().orc_bench_commit_naive(_p(v), C.c_size_t(v.shape[0]), _p(pts))
+
+
+def msm_pippenger(values, points, window_bits=8, slices=4):
+    """best-effort CPU bucket method (all cores); same point as kzg_commit.  -> affine point (12 limbs)"""
+    v = _arr(FR381, values)
+    pts = np.ascontiguousarray(points, np.uint64).reshape(-1, 12)
+    out = np.zeros(12, np.uint64)
+    used = C.c_int(0)
+    _chk(lib().orc_msm_pippenger(_p(v), C.c_size_t(v.shape[0]), _p(pts), window_bits, slices, _p(out), C.byref(used)), "msm_pippenger")
+    return out
+
+
+def bench_pippenger_mt(values, points, window_bits=None, slices=None):
+    """-> (seconds, threads used, window bits): the CPU Pippenger over all host cores"""
+    import os
+    v = _arr(FR381, values)
+    pts = np.ascontiguousarray(points, np.uint64).reshape(-1, 12)
+    n = v.shape[0]
+    cores = os.cpu_count() or 1
+    if window_bits is None:
+        window_bits = max(4, min(12, n.bit_length() - 8))
+    if slices is None:
+        w = (255 + window_bits - 1) // window_bits
+        slices = max(1, (2 * cores + w - 1) // w)
+    out = np.zeros(12, np.uint64)
+    used = C.c_int(0)
+    secs = lib().orc_bench_pippenger_mt(_p(v), C.c_size_t(n), _p(pts), window_bits, slices, _p(out), C.byref(used))
+    if secs < 0:
+        raise OraclePanic(E_ARG, "orc_bench_pippenger_mt")
+    return secs, used.value, window_bits

@@ -335,6 +335,75 @@ def gkr_verify(layers, proof, inputs, p):
 
 
 # ---- BLS12-381 G1, affine big-int arithmetic ------------------------------------------------------
+# ---- the dense definition generalised to per-layer widths (independent oracle of the sparse GKR prover) --------------------
+# The reference ties a layer's width to its index (arithmetic_circuit.rs:166-178: layer i has i bits of `a` and i + 1 bits each
+# of `b`, `c`).  Here layer l has out_bits[l] bits of `a` and in_bits[l] = out_bits[l + 1] (log2 #inputs for the last layer) bits
+# each of `b` and `c`; everything else is the reference's definition, term for term: the wiring predicates are DENSE 0/1 tables
+# indexed a || b || c MSB first (:126-163, :180-196), folded by the output challenges / alpha-beta-combined over rb, rc
+# (gkr_protocol.rs:60-82, utils.rs:23-68), f(b, c) = add(b,c) (W(b) + W(c)) + mul(b,c) (W(b) W(c)) from DENSE outer sums /
+# products (utils.rs:8-21), and the degree-2 sumcheck of sumcheck_gkr_protocol.rs:24-67 over its 2 in_bits variables.  With
+# out_bits[0] = k0 the output claim takes k0 successive challenges (the reference has k0 = 1).  Nothing here knows about gate
+# lists, eq tables or the two-phase split of the product's linear-time prover.
+def circuit_evaluate_wide(layers, out_bits, inputs, p):
+    cur, evs = list(inputs), [list(inputs)]
+    for l in range(len(layers) - 1, -1, -1):              # arithmetic_circuit.rs:72
+        res = [0] * (1 << out_bits[l])
+        for (lft, rgt, o, op) in layers[l]:
+            res[o] = (res[o] + (cur[lft] + cur[rgt] if op == ADD else cur[lft] * cur[rgt])) % p   # :90-96
+        cur = res
+        evs.append(list(cur))
+    evs.reverse()
+    return evs
+
+
+def add_mul_mle_wide(layer, ka, kb):
+    n = 1 << (ka + 2 * kb)
+    add, mul = [0] * n, [0] * n
+    for (lft, rgt, o, op) in layer:
+        (add if op == ADD else mul)[(o << (2 * kb)) | (lft << kb) | rgt] = 1      # a || b || c, MSB first (:180-196)
+    return add, mul
+
+
+def gkr_prove_wide(layers, out_bits, inputs, p):
+    nl = len(layers)
+    in_bits = [out_bits[l + 1] if l + 1 < nl else len(inputs).bit_length() - 1 for l in range(nl)]
+    evs = circuit_evaluate_wide(layers, out_bits, inputs, p)
+    t = Transcript()
+    w0 = list(evs[0])
+    t.append(b"".join(be32(v) for v in w0))               # gkr_protocol.rs:49
+    ra = [t.challenge(p) for _ in range(out_bits[0])]     # :50, one challenge per output variable
+    claim = evaluate(w0, ra, p)                           # :51
+    alpha = beta = 0
+    rb, rc = [], []
+    out = dict(circuit_output=evs[0], output_challenges=ra, layer_claims=[], coeffs=[], challenges=[], wb=[], wc=[])
+    for l, layer in enumerate(layers):
+        add, mul = add_mul_mle_wide(layer, out_bits[l], in_bits[l])
+        if l == 0:
+            add_bc, mul_bc = _fold_all(add, ra, p), _fold_all(mul, ra, p)                   # :60-72
+        else:                                             # utils.rs:23-68
+            add_bc = [(alpha * x + beta * y) % p for x, y in zip(_fold_all(add, rb, p), _fold_all(add, rc, p))]
+            mul_bc = [(alpha * x + beta * y) % p for x, y in zip(_fold_all(mul, rb, p), _fold_all(mul, rc, p))]
+        w = evs[l + 1]
+        fbc = [[add_bc, tensor(w, w, lambda a, b: a + b, p)], [mul_bc, tensor(w, w, lambda a, b: a * b, p)]]   # utils.rs:8-21
+        out["layer_claims"].append(claim)
+        polys, chal = sumcheck_gkr_prove(fbc, claim, t, p)                                  # :99
+        out["coeffs"] += polys
+        out["challenges"] += chal
+        if l < nl - 1:                                    # :109-133
+            mid = len(chal) // 2
+            rb, rc = chal[:mid], chal[mid:]
+            wb, wc = evaluate(w, rb, p), evaluate(w, rc, p)
+            out["wb"].append(wb)
+            out["wc"].append(wc)
+            t.append(be32(wb))
+            alpha = t.challenge(p)
+            t.append(be32(wc))
+            beta = t.challenge(p)
+            claim = (alpha * wb + beta * wc) % p
+    out["claimed_sum"] = claim
+    return out
+
+
 Q = P["bls12_381_fq"]
 R = P["bls12_381_fr"]
 G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,

@@ -193,6 +193,12 @@ int orc_kzg_quotients(const uint64_t *values, size_t len, const uint64_t *openin
 double orc_bench_fold(int field, const uint64_t *table, size_t len, const uint64_t *r, int reps);
 double orc_bench_fold_mt(int field, const uint64_t *table, size_t len, const uint64_t *r, int reps, int *threads_used);
 double orc_bench_commit_naive(const uint64_t *values, size_t len, const uint64_t *g1_points);
+/* best-effort CPU MSM (bucket method, OpenMP over (window, slice) items): same group element as orc_kzg_commit.  Not reference
+ * code (the reference has no MSM routine): the "all cores" CPU baseline of BASELINE.md section 3.2 */
+int orc_msm_pippenger(const uint64_t *values, size_t len, const uint64_t *g1_points, int window_bits, int slices, uint64_t *out12,
+                      int *threads_used);
+double orc_bench_pippenger_mt(const uint64_t *values, size_t len, const uint64_t *g1_points, int window_bits, int slices,
+                              uint64_t *out12, int *threads_used);
 
 #ifdef __cplusplus
 }

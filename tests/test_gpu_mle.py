@@ -166,7 +166,7 @@ def test_stateless_host_buffer_calls(zk):
     assert np.array_equal(ev, O.evaluate(field, tab, pt))
 
 
-# ---- BASELINE sizes: size-independent properties (oracle checks sampled entries + linearity) ---------
+# ---- BASELINE sizes: the WHOLE output table against the oracle + size-independent properties ---------
 @pytest.mark.parametrize("logn", [20, 24])
 def test_full_size_fold_properties(zk, logn):
     field = 0
@@ -195,6 +195,13 @@ def test_full_size_fold_properties(zk, logn):
     padded[m: m + len(idx)] = hi
     want = O.partial_evaluate(field, padded, 0, r)[: len(idx)]
     assert np.array_equal(out[idx], want)
+    # (1b) every element: the oracle folds the host mirror of the whole table (0.5 s of CPU at 2^24)
+    host = np.zeros((n, 4), np.uint64)
+    assert L.zk_host_fill_random(field, 0x5EED0000 + logn, 0, n, host.ctypes.data_as(u64p)) == 0
+    assert np.array_equal(poly.evaluated_values, host)          # device generator == host mirror
+    want_full = O.partial_evaluate(field, host, 0, r)
+    del host
+    assert np.array_equal(out, want_full)
     # (2) linearity checksum: sum(fold(t, r)) == (1 - r) * sum(lo) + r * sum(hi)
     hs = poly.half_sums()
     one = O.from_ints(field, [1])[0]
@@ -203,8 +210,10 @@ def test_full_size_fold_properties(zk, logn):
     assert np.array_equal(lhs, rhs)
     # (3) the fused round kernel gives the same table and the same half sums
     fused, sums = poly.fold_half_sums(r)
-    assert np.array_equal(fused.evaluated_values, out)
+    assert np.array_equal(fused.evaluated_values, want_full)     # whole table of the fused round vs the oracle
+    assert np.array_equal(sums, O.split_and_sum(field, want_full))
     assert np.array_equal(sums, folded.half_sums())
+    del want_full
     # (4) evaluate == chained folds: f(r, x2..xn) evaluated two ways
     point = rand_table(zk, field, logn, 99)
     point[0] = r

@@ -29,6 +29,10 @@ def test_sharded_provers_on_gpu(world, logn):
     for k in ("basic_claimed", "basic_rounds", "basic_chal", "gkr_coeffs", "gkr_chal", "gkr_tail"):
         want["dev_" + k] = want[k]
     want["dev_gkr_final"] = np.stack([O.evaluate(field, sum_tables[p, f], want["gkr_chal"]) for p in range(2) for f in range(2)])
+    want["dev_noabsorb_claimed"] = want["basic_claimed"]
+    want["dev_msm"] = want["msm"]
+    want["dev_evaluate"] = O.evaluate(field, table, table[:logn])
+    want["dev_backend"] = np.frombuffer(b"host-ops", np.uint8)
     check(results, want)
 
 
@@ -60,3 +64,36 @@ def test_prove_succinct_reference_circuits(ref_kats):
         # the opened values are the verifier's wb / wc of the input layer (succinct_gkr_protocol.rs:226-233)
         ch = want["challenges"][-O.gkr_rounds(len(layers) - 1):]
         assert np.array_equal(proof.input_rb_proof.evaluation, O.evaluate(O.FR381, inputs, ch[: len(ch) // 2]))
+
+
+@pytest.mark.parametrize("logn", [3, 13])
+def test_rccl_world_size_1_native_provers(logn):
+    """process group "nccl" (= RCCL) with one rank on the one GPU: the library's own RCCL communicator runs every collective
+    of the sharded provers on the prover's stream; proofs equal the oracle's.  (RCCL refuses two ranks on one device, so
+    more ranks than GPUs go over the exchange callbacks: test_sharded_provers_on_gpu.)"""
+    import os
+    import tempfile
+    import torch.multiprocessing as mp
+    from test_sharded_cpu import free_port
+    from _sharded_workers import run_rccl_world1
+    field = O.FR381
+    n = 1 << logn
+    table = rand_table(field, n, 40 + logn)
+    sum_tables = np.stack([np.stack([rand_table(field, n, 300 * p + 10 * f + logn) for f in range(2)]) for p in range(2)])
+    claimed = O.vec_sum(field, O.sumpoly_reduce(field, sum_tables))
+    g = O.g1_generator()
+    pts = np.stack([O.g1_mul_fr(g, O.from_ints(O.FR381, [11 + 3 * i])[0]) for i in range(8)])
+    scalars = rand_table(O.FR381, 8, 79)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(run_rccl_world1, args=(free_port(), field, table, sum_tables, claimed, scalars, pts, d), nprocs=1, join=True)
+        res = dict(np.load(os.path.join(d, "rank0.npz")))
+    assert res["backend"].tobytes() == b"rccl"
+    assert np.array_equal(res["limbs"], np.arange(27, dtype=np.int64) * 0x1_0000_0001)       # sum over one rank
+    assert np.array_equal(res["points"][0], pts[:2].reshape(-1))
+    want = expected(field, table, sum_tables, claimed)
+    for k in ("basic_claimed", "basic_rounds", "basic_chal", "gkr_coeffs", "gkr_chal", "gkr_tail"):
+        assert np.array_equal(res[k], want[k]), k
+    assert np.array_equal(res["gkr_final"], np.stack([O.evaluate(field, sum_tables[p, f], want["gkr_chal"]) for p in range(2) for f in range(2)]))
+    assert np.array_equal(res["msm"], O.kzg_commit(scalars, pts))
+    assert np.array_equal(res["evaluate"], O.evaluate(field, table, table[:logn]))
+    assert int(res["ncoll"][0]) >= 3

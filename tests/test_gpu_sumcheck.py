@@ -191,8 +191,9 @@ def test_gkr_sumcheck_random_vs_oracle(zk, field, shape):
 
 def test_gkr_sumcheck_large_2p20(zk):
     """4 tables of 2^20 (f(b,c) of a layer with 2^10 wires): proof equals the oracle's"""
-    field, n = 2, 1 << 16
-    tabs = np.stack([np.stack([rand_table(zk, field, n, 70 + 2 * p + f) for f in range(2)]) for p in range(2)])
+    field, n = 2, 1 << 20
+    MP = zk.MultilinearPolynomial
+    tabs = np.stack([np.stack([MP.random(field, n, 70 + 2 * p + f).evaluated_values for f in range(2)]) for p in range(2)])
     sp = mk_sum(zk, field, tabs)
     claimed = O.vec_sum(field, O.sumpoly_reduce(field, tabs))
     result = zk.sumcheck.prove(sp, claimed, zk.Transcript())

@@ -94,3 +94,22 @@ def test_commit_with_zero_scalars_and_infinity_bases():
     f_tau = _eval_at([3, 0, 9, 1, 0, 0, 5, 11], [1, 0, 7])
     assert pt(O.kzg_commit(vals, pts)) == M.g1_mul(M.G1, f_tau)
     assert pt(O.kzg_commit(O.from_ints(O.FR381, [0] * 8), pts)) is None
+
+
+def test_cpu_pippenger_baseline_equals_naive_commit():
+    """the all-cores CPU baseline bench.py times beside the GPU MSM (not reference code) computes the commitment the
+    reference's naive sum does (multilinear_kzg.rs:37-42), incl. zero scalars, infinity and repeated bases"""
+    rng = random.Random(11)
+    g = O.g1_generator()
+    n = 37
+    pts = np.stack([O.g1_mul_fr(g, O.from_ints(O.FR381, [5 + 7 * i])[0]) for i in range(n)])
+    pts[3] = 0                                   # infinity
+    pts[9] = pts[8]
+    ks = [rng.randrange(R) for _ in range(n)]
+    ks[0], ks[1], ks[2] = 0, 1, R - 1
+    sc = O.from_ints(O.FR381, ks)
+    want = O.g1_affine_ints(O.kzg_commit(sc, pts))
+    for c, slices in ((1, 1), (4, 3), (8, 2), (13, 5), (16, 1)):
+        assert O.g1_affine_ints(O.msm_pippenger(sc, pts, c, slices)) == want, (c, slices)
+    secs, threads, c = O.bench_pippenger_mt(sc, pts)
+    assert secs >= 0 and threads >= 1

@@ -39,14 +39,23 @@ def expected(field, table, sum_tables, claimed):
     t = O.Transcript()
     t.append(b"prefix")
     co, gch = O.sumcheck_gkr_prove(field, sum_tables, claimed, t)
+    ta = O.Transcript()
+    ta.append(O.mle_to_bytes(field, table))
     return dict(basic_claimed=cs, basic_rounds=rp, basic_chal=ch, gkr_coeffs=co, gkr_chal=gch,
-                gkr_tail=np.frombuffer(t.sample_random_challenge(), np.uint8))
+                gkr_tail=np.frombuffer(t.sample_random_challenge(), np.uint8),
+                absorb_digest=np.frombuffer(ta.sample_random_challenge(), np.uint8))
 
 
 def check(results, want):
     for res in results:                       # every rank holds the same, reference-identical proof
         for k, v in want.items():
             assert np.array_equal(res[k], v), k
+    # the whole-table absorb is not a bandwidth-sized collective for anyone but the hashing rank: the others receive the
+    # 208-byte sponge (25 lanes + fill) and nothing else
+    for key in ("absorb_rx", "dev_absorb_rx"):
+        for rank, res in enumerate(results):
+            if key in res and len(results) > 1 and rank != 0:
+                assert int(res[key][0]) == 208, (key, rank, res[key])
 
 
 @pytest.mark.parametrize("logn", [1, 2, 3, 6])

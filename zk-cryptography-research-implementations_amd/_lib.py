@@ -7,7 +7,7 @@ FIELD_NAMES = {FR381: "bls12_381_fr", FQ381: "bls12_381_fq", BN254_FQ: "bn254_fq
 
 ZK_OK = 0
 ZK_E_NOT_POW2, ZK_E_LEN_MISMATCH, ZK_E_NVARS, ZK_E_NEED_TWO, ZK_E_KZG_LEN, ZK_E_RANGE = -1, -2, -3, -4, -5, -6
-ZK_E_ARG, ZK_E_NOMEM, ZK_E_NO_DEVICE, ZK_E_HIP, ZK_E_NOT_INIT = -7, -8, -9, -10, -11
+ZK_E_ARG, ZK_E_NOMEM, ZK_E_NO_DEVICE, ZK_E_HIP, ZK_E_NOT_INIT, ZK_E_COMM = -7, -8, -9, -10, -11, -12
 _PANIC_CODES = {ZK_E_NOT_POW2, ZK_E_LEN_MISMATCH, ZK_E_NVARS, ZK_E_NEED_TWO, ZK_E_KZG_LEN, ZK_E_RANGE, ZK_E_NOT_INIT}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -69,6 +69,7 @@ def lib():
         "zk_table_wrap": [C.c_int, vp, sz, C.POINTER(vp)],
         "zk_table_clone": [vp, C.POINTER(vp)],
         "zk_table_fill_random": [vp, C.c_uint64],
+        "zk_table_fill_random_strided": [vp, C.c_uint64, sz, sz],
         "zk_host_fill_random": [C.c_int, C.c_uint64, sz, sz, u64p],
         "zk_mle_fold": [vp, sz, u64p, vp, vp],
         "zk_mle_fold_ptr": [C.c_int, vp, sz, sz, u64p, vp, vp],
@@ -104,7 +105,7 @@ def check(rc):
         return
     L = lib()
     msg = L.zk_status_message(rc).decode()
-    if rc == ZK_E_HIP or rc == ZK_E_NO_DEVICE:
+    if rc == ZK_E_HIP or rc == ZK_E_NO_DEVICE or rc == ZK_E_COMM:
         msg += ": " + L.zk_last_error().decode()
     raise (ReferencePanic if rc in _PANIC_CODES else ZkError)(rc, msg)
 

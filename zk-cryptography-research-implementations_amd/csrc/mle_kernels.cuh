@@ -42,10 +42,10 @@ template <class F> ZK_HD Fe<F> random_element(uint64_t seed, uint64_t idx) {
     e.l[F::N - 1] &= (bits >= 2) ? ((1u << (bits - 1)) - 1u) : 0u;
     return e;
 }
-template <class F> __global__ void fill_random_kernel(void *out, size_t len, uint64_t seed, size_t first) {
+template <class F> __global__ void fill_random_kernel(void *out, size_t len, uint64_t seed, size_t first, size_t step = 1) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride)
-        fe_store<F>(out, i, random_element<F>(seed, first + i));
+        fe_store<F>(out, i, random_element<F>(seed, first + i * step));
 }
 
 // a loop-invariant multiplier (the round challenge r): converted once per lane to the 29-bit form

@@ -190,6 +190,7 @@ const char *zk_status_message(int status) {
         case ZK_E_NO_DEVICE: return "no usable HIP device (libzkmle_amd has no CPU fallback)";
         case ZK_E_HIP: return "HIP runtime error";
         case ZK_E_NOT_INIT: return "Can't prove without init";
+        case ZK_E_COMM: return "communicator error (RCCL or exchange callback)";
         default: return "unknown status";
     }
 }
@@ -296,6 +297,13 @@ int zk_table_fill_random(zk_table *t, uint64_t seed) {
     if (!t) return ZK_E_ARG;
     ZK_TRY(require_device());
     ZK_DISPATCH_FIELD(t->field, (fill_random_kernel<F><<<grid_for(t->len), kBlock, 0, cur_stream()>>>(t->dptr, t->len, seed, 0)));
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+int zk_table_fill_random_strided(zk_table *t, uint64_t seed, size_t first, size_t stride) {
+    if (!t || stride == 0) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(t->field, (fill_random_kernel<F><<<grid_for(t->len), kBlock, 0, cur_stream()>>>(t->dptr, t->len, seed, first, stride)));
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }

@@ -1,0 +1,520 @@
+// zkmle_sharded.hip -- C ABI: the multi-GPU provers (one process per GPU) and their communicator.
+//
+// the tables shard by the LOW index bits (rank g of G holds the entries i == g mod G as a contiguous local table),
+// so every round that folds variable 0 (prover.rs:62, sumcheck_gkr_protocol.rs:57) is local and the only per-round exchange is
+// the sum over the ranks of 2 (basic) or d + 1 (GKR) evaluations.  Here that sum is ONE ncclAllReduce(ncclInt64, ncclSum) of
+// (d + 1) x 9 words in device memory, enqueued on the prover's stream between the producer kernel and the transcript kernel
+// (dev_transcript.cuh limbs_finish_kernel): RCCL over xGMI, no host round trip inside a sumcheck.  Once the GLOBAL table has
+// <= kTailLen entries the ranks all-gather what is left and every rank finishes the proof replicated in one launch
+// (sumcheck_tail_kernel), so the latency-bound small rounds cost no collective at all.
+// RCCL is opened with dlopen at first use (librccl.so.1): single-GPU users never load it.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "context.h"
+#include "mle_kernels.cuh"
+#include "transcript.h"
+
+using namespace zk;
+
+namespace {
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------
+struct RcclApi {
+    void *lib = nullptr;
+    std::string err;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+};
+
+RcclApi &rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy the process already holds (e.g. the one PyTorch ships) wins: one RCCL per process
+        const char *names[] = {getenv("ZK_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (api.lib) break;
+        }
+        for (const char *n : names) {
+            if (api.lib) break;
+            if (!n || !*n) continue;
+            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!api.lib) { api.err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
+#define ZK_SYM(field, name)                                                              \
+    api.field = (decltype(api.field))dlsym(api.lib, name);                               \
+    if (!api.field && api.err.empty()) api.err = std::string("RCCL symbol missing: ") + name;
+        ZK_SYM(GetUniqueId, "ncclGetUniqueId")
+        ZK_SYM(CommInitRank, "ncclCommInitRank")
+        ZK_SYM(CommDestroy, "ncclCommDestroy")
+        ZK_SYM(GetErrorString, "ncclGetErrorString")
+        ZK_SYM(AllReduce, "ncclAllReduce")
+        ZK_SYM(AllGather, "ncclAllGather")
+        ZK_SYM(Broadcast, "ncclBroadcast")
+        ZK_SYM(Send, "ncclSend")
+        ZK_SYM(Recv, "ncclRecv")
+        ZK_SYM(GroupStart, "ncclGroupStart")
+        ZK_SYM(GroupEnd, "ncclGroupEnd")
+#undef ZK_SYM
+    });
+    return api;
+}
+
+int rccl_ready() {
+    RcclApi &a = rccl();
+    if (!a.lib || !a.err.empty()) { set_last_error(a.err); return ZK_E_COMM; }
+    return ZK_OK;
+}
+
+#define ZK_NCCL(call)                                                                                        \
+    do {                                                                                                     \
+        ncclResult_t r__ = (call);                                                                           \
+        if (r__ != ncclSuccess) {                                                                            \
+            set_last_error(std::string(#call) + ": " + rccl().GetErrorString(r__));                          \
+            return ZK_E_COMM;                                                                                \
+        }                                                                                                    \
+    } while (0)
+
+#define ZK_CB(call, what)                                                                                    \
+    do {                                                                                                     \
+        if ((call) != 0) { set_last_error(std::string("exchange callback failed: ") + what); return ZK_E_COMM; } \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { pool_free(p); }
+    int alloc(size_t bytes) { return pool_alloc(bytes, &p); }
+};
+
+struct TableSet {     // pooled temporaries, freed with the set
+    std::vector<zk_table *> t;
+    ~TableSet() { for (zk_table *x : t) zk_table_free(x); }
+    int alloc(int field, size_t len, size_t count) {
+        for (size_t k = 0; k < count; k++) {
+            zk_table *x = nullptr;
+            ZK_TRY(table_alloc_pooled(field, len, &x));
+            t.push_back(x);
+        }
+        return ZK_OK;
+    }
+};
+
+}  // namespace
+
+struct zk_comm {
+    int kind;                 // 0 = RCCL, 1 = host callbacks
+    int nranks, rank;
+    ncclComm_t nccl;
+    zk_comm_host_ops ops;
+    uint64_t bytes_rx, ncoll;
+    std::vector<uint8_t> hs, hr;     // host staging of the callback kind
+
+    int all_reduce_i64(void *dev, size_t count) {
+        ncoll++;
+        bytes_rx += nranks > 1 ? count * 8 : 0;
+        if (kind == 0) {
+            ZK_NCCL(rccl().AllReduce(dev, dev, count, ncclInt64, ncclSum, nccl, cur_stream()));
+            return ZK_OK;
+        }
+        if (nranks == 1) return ZK_OK;
+        hs.resize(count * 8);
+        ZK_HIP(memcpy_on_stream(hs.data(), dev, count * 8, hipMemcpyDeviceToHost));
+        ZK_CB(ops.all_reduce_sum_i64(ops.ctx, (int64_t *)hs.data(), count), "all_reduce_sum_i64");
+        ZK_HIP(memcpy_on_stream(dev, hs.data(), count * 8, hipMemcpyHostToDevice));
+        return ZK_OK;
+    }
+    int all_gather(const void *dev_send, void *dev_recv, size_t bytes) {
+        ncoll++;
+        bytes_rx += (uint64_t)(nranks - 1) * bytes;
+        if (kind == 0) {
+            ZK_NCCL(rccl().AllGather(dev_send, dev_recv, bytes, ncclUint8, nccl, cur_stream()));
+            return ZK_OK;
+        }
+        if (nranks == 1) {
+            ZK_HIP(hipMemcpyAsync(dev_recv, dev_send, bytes, hipMemcpyDeviceToDevice, cur_stream()));
+            return ZK_OK;
+        }
+        hs.resize(bytes);
+        hr.resize(bytes * (size_t)nranks);
+        ZK_HIP(memcpy_on_stream(hs.data(), dev_send, bytes, hipMemcpyDeviceToHost));
+        ZK_CB(ops.all_gather(ops.ctx, hs.data(), hr.data(), bytes), "all_gather");
+        ZK_HIP(memcpy_on_stream(dev_recv, hr.data(), hr.size(), hipMemcpyHostToDevice));
+        return ZK_OK;
+    }
+    // dev_recv (root only): nranks x bytes in rank order
+    int gather(const void *dev_send, void *dev_recv, size_t bytes, int root) {
+        ncoll++;
+        if (rank == root) bytes_rx += (uint64_t)(nranks - 1) * bytes;
+        if (kind == 0) {
+            if (rank == root) {
+                ZK_HIP(hipMemcpyAsync((char *)dev_recv + (size_t)root * bytes, dev_send, bytes, hipMemcpyDeviceToDevice, cur_stream()));
+                if (nranks == 1) return ZK_OK;
+                ZK_NCCL(rccl().GroupStart());
+                for (int p = 0; p < nranks; p++)
+                    if (p != root) ZK_NCCL(rccl().Recv((char *)dev_recv + (size_t)p * bytes, bytes, ncclUint8, p, nccl, cur_stream()));
+                ZK_NCCL(rccl().GroupEnd());
+            } else {
+                ZK_NCCL(rccl().Send(dev_send, bytes, ncclUint8, root, nccl, cur_stream()));
+            }
+            return ZK_OK;
+        }
+        if (nranks == 1) {
+            ZK_HIP(hipMemcpyAsync(dev_recv, dev_send, bytes, hipMemcpyDeviceToDevice, cur_stream()));
+            return ZK_OK;
+        }
+        hs.resize(bytes);
+        ZK_HIP(memcpy_on_stream(hs.data(), dev_send, bytes, hipMemcpyDeviceToHost));
+        if (rank == root) hr.resize(bytes * (size_t)nranks);
+        ZK_CB(ops.gather(ops.ctx, hs.data(), rank == root ? hr.data() : nullptr, bytes, root), "gather");
+        if (rank == root) ZK_HIP(memcpy_on_stream(dev_recv, hr.data(), bytes * (size_t)nranks, hipMemcpyHostToDevice));
+        return ZK_OK;
+    }
+    int broadcast(void *dev, size_t bytes, int root) {
+        ncoll++;
+        if (rank != root) bytes_rx += bytes;
+        if (kind == 0) {
+            ZK_NCCL(rccl().Broadcast(dev, dev, bytes, ncclUint8, root, nccl, cur_stream()));
+            return ZK_OK;
+        }
+        if (nranks == 1) return ZK_OK;
+        hs.resize(bytes);
+        if (rank == root) ZK_HIP(memcpy_on_stream(hs.data(), dev, bytes, hipMemcpyDeviceToHost));
+        ZK_CB(ops.broadcast(ops.ctx, hs.data(), bytes, root), "broadcast");
+        if (rank != root) ZK_HIP(memcpy_on_stream(dev, hs.data(), bytes, hipMemcpyHostToDevice));
+        return ZK_OK;
+    }
+};
+
+namespace {
+
+// rep[k][j * G + r] = recv[r][k][j]: the gathered local tables (send layout: ntab tables of L entries, one after the other)
+// interleaved back into global index order (global i = j G + r).  One lane per 16-byte word.
+__global__ void interleave_kernel(const uint4 *__restrict__ recv, uint4 *__restrict__ rep, size_t ntab, size_t L, size_t G, int words) {
+    size_t total = ntab * L * G * (size_t)words, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t w = i % words, e = i / words;           // e = output element index: (k, j, r)
+        size_t r = e % G, j = (e / G) % L, k = e / (G * L);
+        rep[i] = recv[((r * ntab + k) * L + j) * words + w];
+    }
+}
+
+struct Sponge208 {            // what rank 0 broadcasts after the table absorb: 25 lanes + block fill
+    uint64_t a[25];
+    uint64_t fill;
+};
+
+// transcript.append(convert_to_bytes(table)) (prover.rs:38-39) for a table sharded over the ranks: every rank converts its
+// entries to canonical big-endian bytes on its GPU and streams them to rank 0 chunk by chunk; rank 0 interleaves a chunk back
+// into global order on its GPU, copies it to a pinned buffer and absorbs it while the next chunk is in flight; at the end the
+// sponge state (208 bytes) is broadcast.  The sponge is sequential, so one rank has to see every byte; nobody else does.
+template <class F> int sharded_absorb(zk_comm *c, Transcript &tr, const zk_table *shard) {
+    const size_t esz = 4 * F::N, L = shard->len, G = (size_t)c->nranks;
+    if (G == 1) return transcript_absorb_table(tr, shard);
+    const bool root = c->rank == 0;
+    size_t cl = ((size_t)1 << 18) / G;                    // local elements per chunk: 8 MiB of global bytes per chunk
+    if (cl < 1) cl = 1;
+    if (cl > L) cl = L;
+    DevBuf snd[2], rcv[2], il[2];
+    void *host[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; b++) {
+        ZK_TRY(snd[b].alloc(cl * esz));
+        if (root) {
+            ZK_TRY(rcv[b].alloc(G * cl * esz));
+            ZK_TRY(il[b].alloc(G * cl * esz));
+        }
+    }
+    if (root) {
+        ZK_TRY(pinned_pair(((size_t)1 << 18) * 4 * Fq381::N, host));
+        ZK_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    }
+    int rc = ZK_OK, pending = -1;
+    size_t pending_bytes = 0;
+    for (size_t off = 0, k = 0; off < L && rc == ZK_OK; off += cl, k++) {
+        const int b = (int)(k & 1);
+        const size_t n = L - off < cl ? L - off : cl;
+        elementwise_kernel<F, OP_TO_CANONICAL_BE><<<grid_for(n), kBlock, 0, cur_stream()>>>((const char *)shard->dptr + off * esz, nullptr, snd[b].p, n, fe_zero<F>());
+        if (hipGetLastError() != hipSuccess) { rc = ZK_E_HIP; break; }
+        rc = c->gather(snd[b].p, root ? rcv[b].p : nullptr, n * esz, 0);
+        if (rc != ZK_OK || !root) continue;
+        interleave_kernel<<<grid_for(n * G * (esz / 16)), kBlock, 0, cur_stream()>>>((const uint4 *)rcv[b].p, (uint4 *)il[b].p, 1, n, G, (int)(esz / 16));
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(host[b], il[b].p, n * G * esz, hipMemcpyDeviceToHost, cur_stream());
+        if (e == hipSuccess) e = hipEventRecord(ev[b], cur_stream());
+        if (e == hipSuccess && pending >= 0) {
+            e = hipEventSynchronize(ev[pending]);
+            if (e == hipSuccess) tr.append((const uint8_t *)host[pending], pending_bytes);
+        }
+        if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; break; }
+        pending = b;
+        pending_bytes = n * G * esz;
+    }
+    if (root && rc == ZK_OK && pending >= 0) {
+        hipError_t e = hipEventSynchronize(ev[pending]);
+        if (e == hipSuccess) tr.append((const uint8_t *)host[pending], pending_bytes);
+        else { set_last_error(hipGetErrorString(e)); rc = ZK_E_HIP; }
+    }
+    if (root) {
+        (void)hipEventDestroy(ev[0]);
+        (void)hipEventDestroy(ev[1]);
+    }
+    ZK_TRY(rc);
+    // the sponge after the absorb: rank 0 -> everyone
+    DevBuf st;
+    ZK_TRY(st.alloc(sizeof(Sponge208)));
+    Sponge208 sp{};
+    if (root) {
+        uint32_t fill = 0;
+        tr.sponge().export_state(sp.a, &fill);
+        sp.fill = fill;
+        ZK_HIP(memcpy_on_stream(st.p, &sp, sizeof sp, hipMemcpyHostToDevice));
+    }
+    ZK_TRY(c->broadcast(st.p, sizeof sp, 0));
+    if (!root) {
+        ZK_HIP(memcpy_on_stream(&sp, st.p, sizeof sp, hipMemcpyDeviceToHost));
+        tr.sponge().import_state(sp.a, (uint32_t)sp.fill);
+    } else {
+        ZK_HIP(hipStreamSynchronize(cur_stream()));
+    }
+    return ZK_OK;
+}
+
+// The rounds of a sharded sumcheck (mode 0: basic, one table; mode 1: GKR sumcheck on nprod x nfac tables), driven through the
+// zk_rounds handle (zkmle_sumcheck.hip).  `t` holds everything absorbed before the rounds and gets the sponge back.
+int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs, size_t nprod, size_t nfac, zk_transcript *t,
+                   uint64_t *claimed, uint64_t *messages, uint64_t *challenges, uint64_t *final_values) {
+    const size_t ntab = nprod * nfac, G = (size_t)c->nranks, esz = (size_t)field_limbs64(field) * 8;
+    size_t L = tabs[0]->len;
+    const size_t nrounds = ilog2(L) + ilog2(G);
+    if (G > 1024 || !is_pow2(G)) return ZK_E_ARG;
+    zk_rounds *r = nullptr;
+    ZK_TRY(zk_rounds_new(field, mode, nprod, nfac, nrounds, t, &r));
+    struct Guard { zk_rounds *r; ~Guard() { zk_rounds_free(r); } } guard{r};
+    DevBuf limbs;
+    ZK_TRY(limbs.alloc(zk_rounds_limbs_len(r) * 8));
+    uint64_t *lp = (uint64_t *)limbs.p;
+    const size_t kTail = 2048;                                           // kTailLen (dev_transcript.cuh): one-launch replicated tail
+    TableSet ping, pong;
+    std::vector<const zk_table *> cur(tabs, tabs + ntab);
+    bool absorbed = false;                                               // the evaluations of `cur` are in the transcript
+    if (L * G > kTail) {
+        ZK_TRY(ping.alloc(field, L / 2, ntab));
+        ZK_TRY(pong.alloc(field, L / 4 ? L / 4 : 1, ntab));
+        ZK_TRY(zk_rounds_evals(r, cur.data(), lp));
+        ZK_TRY(c->all_reduce_i64(lp, zk_rounds_limbs_len(r)));           // the round's only exchange, on the stream
+        ZK_TRY(zk_rounds_absorb(r, lp));
+        absorbed = true;
+        TableSet *dst = &ping, *other = &pong;
+        while (L * G > kTail) {                                          // local rounds: fold + next evaluations, all-reduce, transcript
+            ZK_TRY(zk_rounds_fold_evals(r, cur.data(), dst->t.data(), lp));
+            ZK_TRY(c->all_reduce_i64(lp, zk_rounds_limbs_len(r)));
+            ZK_TRY(zk_rounds_absorb(r, lp));
+            for (size_t k = 0; k < ntab; k++) cur[k] = dst->t[k];
+            TableSet *x = dst; dst = other; other = x;
+            L /= 2;
+        }
+    }
+    if (G == 1) {                                                        // the local table IS the global table
+        if (!absorbed) {
+            ZK_TRY(zk_rounds_evals(r, cur.data(), lp));
+            ZK_TRY(c->all_reduce_i64(lp, zk_rounds_limbs_len(r)));       // a one-rank RCCL communicator still runs its collective
+            ZK_TRY(zk_rounds_absorb(r, lp));
+        }
+        ZK_TRY(zk_rounds_tail(r, cur.data()));
+        return zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+    }
+    // <= kTailLen entries left in the global table: gather them on every rank (global index = j G + rank) and finish replicated
+    DevBuf snd, rcv;
+    ZK_TRY(snd.alloc(ntab * L * esz));
+    ZK_TRY(rcv.alloc(G * ntab * L * esz));
+    for (size_t k = 0; k < ntab; k++)
+        ZK_HIP(hipMemcpyAsync((char *)snd.p + k * L * esz, cur[k]->dptr, L * esz, hipMemcpyDeviceToDevice, cur_stream()));
+    ZK_TRY(c->all_gather(snd.p, rcv.p, ntab * L * esz));
+    DevBuf repbuf;                                                       // one block, ntab replicated tables inside
+    ZK_TRY(repbuf.alloc(ntab * L * G * esz));
+    interleave_kernel<<<grid_for(ntab * L * G * (esz / 16)), kBlock, 0, cur_stream()>>>((const uint4 *)rcv.p, (uint4 *)repbuf.p, ntab, L, G, (int)(esz / 16));
+    ZK_HIP(hipGetLastError());
+    std::vector<zk_table> views(ntab);
+    std::vector<const zk_table *> vp(ntab);
+    for (size_t k = 0; k < ntab; k++) {
+        views[k] = zk_table{field, L * G, (char *)repbuf.p + k * L * G * esz, 0};
+        vp[k] = &views[k];
+    }
+    if (!absorbed) {                                                     // small from the start: first evaluations, already global
+        ZK_TRY(zk_rounds_evals(r, vp.data(), lp));
+        ZK_TRY(zk_rounds_absorb(r, lp));
+    }
+    ZK_TRY(zk_rounds_tail(r, vp.data()));
+    return zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+}
+
+}  // namespace
+
+extern "C" {
+
+int zk_comm_unique_id(uint8_t out128[128]) {
+    if (!out128) return ZK_E_ARG;
+    ZK_TRY(rccl_ready());
+    ncclUniqueId id;
+    static_assert(sizeof(id) == 128, "ncclUniqueId");
+    ZK_NCCL(rccl().GetUniqueId(&id));
+    memcpy(out128, &id, 128);
+    return ZK_OK;
+}
+int zk_comm_init_rccl(const uint8_t id128[128], int nranks, int rank, zk_comm **out) {
+    if (!id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    ZK_TRY(rccl_ready());
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t comm = nullptr;
+    ZK_NCCL(rccl().CommInitRank(&comm, nranks, id, rank));
+    *out = new zk_comm{0, nranks, rank, comm, zk_comm_host_ops{}, 0, 0, {}, {}};
+    return ZK_OK;
+}
+int zk_comm_from_host_ops(const zk_comm_host_ops *ops, int nranks, int rank, zk_comm **out) {
+    if (!ops || !out || nranks < 1 || rank < 0 || rank >= nranks) return ZK_E_ARG;
+    if (nranks > 1 && (!ops->all_reduce_sum_i64 || !ops->all_gather || !ops->gather || !ops->broadcast)) return ZK_E_ARG;
+    *out = new zk_comm{1, nranks, rank, nullptr, *ops, 0, 0, {}, {}};
+    return ZK_OK;
+}
+int zk_comm_free(zk_comm *c) {
+    if (!c) return ZK_OK;
+    if (c->kind == 0 && c->nccl) (void)rccl().CommDestroy(c->nccl);
+    delete c;
+    return ZK_OK;
+}
+int zk_comm_rank(const zk_comm *c) { return c ? c->rank : -1; }
+int zk_comm_size(const zk_comm *c) { return c ? c->nranks : -1; }
+const char *zk_comm_backend(const zk_comm *c) { return !c ? "" : c->kind == 0 ? "rccl" : "host-ops"; }
+int zk_comm_stats(const zk_comm *c, uint64_t *bytes_received, uint64_t *collectives) {
+    if (!c) return ZK_E_ARG;
+    if (bytes_received) *bytes_received = c->bytes_rx;
+    if (collectives) *collectives = c->ncoll;
+    return ZK_OK;
+}
+int zk_comm_all_reduce_sum_i64(zk_comm *c, void *dev_buf, size_t count) {
+    if (!c || !dev_buf) return ZK_E_ARG;
+    return c->all_reduce_i64(dev_buf, count);
+}
+int zk_comm_all_gather(zk_comm *c, const void *dev_send, void *dev_recv, size_t bytes) {
+    if (!c || !dev_send || !dev_recv) return ZK_E_ARG;
+    return c->all_gather(dev_send, dev_recv, bytes);
+}
+int zk_comm_broadcast(zk_comm *c, void *dev_buf, size_t bytes, int root) {
+    if (!c || !dev_buf || root < 0 || root >= c->nranks) return ZK_E_ARG;
+    return c->broadcast(dev_buf, bytes, root);
+}
+
+int zk_sharded_sumcheck_basic_prove(zk_comm *c, const zk_table *shard, int absorb_table, uint64_t *claimed_sum, uint64_t *round_polys,
+                                    uint64_t *challenges) {
+    if (!c || !shard || !claimed_sum || !round_polys) return ZK_E_ARG;
+    if (!is_pow2(shard->len)) return ZK_E_NOT_POW2;                       // Prover::init -> MultilinearPolynomial::new (prover.rs:23)
+    if (!is_pow2((size_t)c->nranks)) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    zk_transcript t;
+    if (absorb_table) ZK_DISPATCH_FIELD(shard->field, ZK_TRY(sharded_absorb<F>(c, t.t, shard)));   // prover.rs:38-39
+    if (shard->len * (size_t)c->nranks == 1) {                            // zero variables: the sum is the entry, no rounds
+        ZK_HIP(memcpy_on_stream(claimed_sum, shard->dptr, (size_t)field_limbs64(shard->field) * 8, hipMemcpyDeviceToHost));
+        return ZK_OK;
+    }
+    const zk_table *tabs[1] = {shard};
+    return sharded_rounds(c, shard->field, 0, tabs, 1, 1, &t, claimed_sum, round_polys, challenges, nullptr);
+}
+
+int zk_sharded_sumcheck_gkr_prove(zk_comm *c, const zk_table *const *shards, size_t nprod, size_t nfac, const uint64_t *claimed_sum,
+                                  zk_transcript *t, uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values) {
+    if (!c || !shards || !claimed_sum || !t || !round_coeffs || !challenges) return ZK_E_ARG;
+    if (nprod == 0 || nfac == 0 || nprod * nfac > 64) return ZK_E_ARG;
+    for (size_t k = 0; k < nprod * nfac; k++) {
+        if (!shards[k] || shards[k]->field != shards[0]->field) return ZK_E_ARG;
+        if (!is_pow2(shards[k]->len)) return ZK_E_NOT_POW2;
+        if (shards[k]->len != shards[0]->len) return ZK_E_NVARS;          // sum_polynomial.rs:17-23
+    }
+    if (!is_pow2((size_t)c->nranks)) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    const int field = shards[0]->field;
+    const size_t L64 = (size_t)field_limbs64(field);
+    uint8_t be[48];
+    ZK_TRY(zk_fe_to_bytes_be(field, claimed_sum, be));
+    t->t.append(be, L64 * 8);                                             // sumcheck_gkr_protocol.rs:35
+    if (shards[0]->len * (size_t)c->nranks == 1) {
+        if (final_values)
+            for (size_t k = 0; k < nprod * nfac; k++)
+                ZK_HIP(memcpy_on_stream(final_values + k * L64, shards[k]->dptr, L64 * 8, hipMemcpyDeviceToHost));
+        return ZK_OK;
+    }
+    if (nprod < 2 || nfac < 2) return ZK_E_NEED_TWO;                      // generate_round_univariate panics (sum_polynomial.rs:58-61)
+    return sharded_rounds(c, field, 1, shards, nprod, nfac, t, nullptr, round_coeffs, challenges, final_values);
+}
+
+int zk_sharded_mle_evaluate(zk_comm *c, const zk_table *shard, const uint64_t *values, size_t nvalues, uint64_t *out) {
+    if (!c || !shard || (!values && nvalues) || !out) return ZK_E_ARG;
+    if (!is_pow2(shard->len) || !is_pow2((size_t)c->nranks)) return ZK_E_NOT_POW2;
+    ZK_TRY(require_device());
+    const size_t G = (size_t)c->nranks, m = ilog2(shard->len), k = ilog2(G);
+    if (nvalues != m + k) return ZK_E_RANGE;
+    const int field = shard->field;
+    const size_t L64 = (size_t)field_limbs64(field), esz = L64 * 8;
+    TableSet tmp;
+    const zk_table *cur = shard;
+    if (m > 0) {
+        ZK_TRY(tmp.alloc(field, shard->len / 2, 1));
+        ZK_TRY(tmp.alloc(field, shard->len / 4 ? shard->len / 4 : 1, 1));
+        for (size_t i = 0; i < m; i++) {                                  // evaluation_form.rs:27-29, local: variable 0 pairs equal low bits
+            zk_table *dst = tmp.t[i & 1];
+            ZK_TRY(zk_mle_fold(cur, 0, values + i * L64, dst, nullptr));
+            cur = dst;
+        }
+    }
+    DevBuf all;
+    ZK_TRY(all.alloc(G * esz));
+    ZK_TRY(c->all_gather(cur->dptr, all.p, esz));                         // entry g = rank g's value = global index g
+    zk_table rep{field, G, all.p, 0};
+    return zk_mle_evaluate(&rep, values + m * L64, k, out);
+}
+
+int zk_sharded_msm_g1(zk_comm *c, const zk_table *scalars_slice, const zk_g1_bases *bases_slice, int window_bits, uint64_t *out12,
+                      zk_msm_stats *stats) {
+    if (!c || !scalars_slice || !bases_slice || !out12) return ZK_E_ARG;
+    uint64_t mine[12];
+    ZK_TRY(zk_msm_g1(scalars_slice, bases_slice, window_bits, mine, stats));
+    const size_t G = (size_t)c->nranks;
+    DevBuf snd, rcv;
+    ZK_TRY(snd.alloc(96));
+    ZK_TRY(rcv.alloc(96 * G));
+    ZK_HIP(memcpy_on_stream(snd.p, mine, 96, hipMemcpyHostToDevice));
+    ZK_TRY(c->all_gather(snd.p, rcv.p, 96));                              // G affine points, 96 B each
+    std::vector<uint64_t> all(12 * G);
+    ZK_HIP(memcpy_on_stream(all.data(), rcv.p, 96 * G, hipMemcpyDeviceToHost));
+    uint64_t acc[12];
+    memcpy(acc, all.data(), 96);
+    for (size_t g = 1; g < G; g++) {                                      // G - 1 additions, same order on every rank
+        uint64_t nx[12];
+        ZK_TRY(zk_g1_add(acc, all.data() + 12 * g, nx));
+        memcpy(acc, nx, 96);
+    }
+    memcpy(out12, acc, 96);
+    return ZK_OK;
+}
+
+}  // extern "C"

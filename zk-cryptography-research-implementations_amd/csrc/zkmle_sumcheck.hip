@@ -584,6 +584,16 @@ int zk_transcript_challenge(zk_transcript *t, int field, uint64_t *out) {
     ZK_DISPATCH_FIELD(field, store_el<F>(out, t->t.random_challenge_as_field_element<F>()));
     return ZK_OK;
 }
+int zk_transcript_export_state(const zk_transcript *t, uint64_t lanes25[25], uint32_t *fill) {
+    if (!t || !lanes25 || !fill) return ZK_E_ARG;
+    const_cast<zk_transcript *>(t)->t.sponge().export_state(lanes25, fill);
+    return ZK_OK;
+}
+int zk_transcript_import_state(zk_transcript *t, const uint64_t lanes25[25], uint32_t fill) {
+    if (!t || !lanes25 || fill >= 136) return ZK_E_ARG;
+    t->t.sponge().import_state(lanes25, fill);
+    return ZK_OK;
+}
 int zk_keccak256(const uint8_t *data, size_t n, uint8_t out32[32]) {
     if ((!data && n) || !out32) return ZK_E_ARG;
     Keccak256 h;

@@ -9,7 +9,14 @@ tests.  Every rank combines the gathered partial sums and runs the same transcri
 broadcast is needed.  The last k rounds run on the gathered G-element table.
 The MSM shards by slices: one Pippenger per rank, one all-gather of G affine points, G - 1 additions.
 
-The per-shard compute goes through an `engine` (GpuShard below: HIP kernels via the C ABI).
+Two layers:
+  * the product path -- `*_prove_device`, `mle_evaluate`, `msm`: ONE call each into the C ABI (include/zkmle.h
+    `zk_sharded_*`, csrc/zkmle_sharded.hip), where the rounds, the RCCL all-reduce of the limb sums and the transcript
+    kernel are enqueued back to back on the prover's stream; `Comm.native()` hands the library its communicator
+    (an RCCL communicator of its own when the process group is "nccl", exchange callbacks over the group otherwise);
+  * the host-driven reference flow of the same protocol (`sumcheck_basic_prove`, `sumcheck_gkr_prove`: one all-gather
+    per round from Python, per-shard compute through an `engine`), kept because it runs with a CPU test double where
+    there is no GPU (tests/test_sharded_cpu.py) and documents the exchange step by step.
 """
 import ctypes as C
 
@@ -44,6 +51,15 @@ def fe_to_bytes_le(field, a):
     return fe_to_bytes_be(field, a)[::-1]
 
 
+class HostOps(C.Structure):
+    """zk_comm_host_ops (include/zkmle.h): exchange callbacks on HOST memory"""
+    _fields_ = [("ctx", C.c_void_p),
+                ("all_reduce_sum_i64", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_size_t)),
+                ("all_gather", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("gather", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)),
+                ("broadcast", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int))]
+
+
 def _declare_host():
     lib = L.lib()
     if getattr(lib, "_sharded_declared", False):
@@ -57,17 +73,24 @@ def _declare_host():
     lib.zk_sumpoly_fold_round_evals.argtypes = [C.POINTER(L.vp), C.POINTER(L.vp), L.sz, L.sz, u64p, u64p]
     lib.zk_sumpoly_fold_round_evals.restype = C.c_int
     vpp = C.POINTER(L.vp)
-    lib.zk_rounds_new.argtypes = [C.c_int, C.c_int, L.sz, L.sz, L.sz, L.vp, vpp]
-    lib.zk_rounds_free.argtypes = [L.vp]
-    lib.zk_rounds_limbs_len.argtypes = [L.vp]
-    lib.zk_rounds_limbs_len.restype = C.c_size_t
-    lib.zk_rounds_evals.argtypes = [L.vp, vpp, C.c_void_p]
-    lib.zk_rounds_fold_evals.argtypes = [L.vp, vpp, vpp, C.c_void_p]
-    lib.zk_rounds_absorb.argtypes = [L.vp, C.c_void_p]
-    lib.zk_rounds_tail.argtypes = [L.vp, vpp]
-    lib.zk_rounds_collect.argtypes = [L.vp, L.vp, u64p, u64p, u64p, u64p]
-    for name in ("zk_rounds_new", "zk_rounds_free", "zk_rounds_evals", "zk_rounds_fold_evals", "zk_rounds_absorb", "zk_rounds_tail",
-                 "zk_rounds_collect"):
+    u8p, i64p = L.u8p, C.POINTER(C.c_int64)
+    lib.zk_comm_unique_id.argtypes = [u8p]
+    lib.zk_comm_init_rccl.argtypes = [u8p, C.c_int, C.c_int, vpp]
+    lib.zk_comm_from_host_ops.argtypes = [C.POINTER(HostOps), C.c_int, C.c_int, vpp]
+    lib.zk_comm_free.argtypes = [L.vp]
+    lib.zk_comm_backend.argtypes = [L.vp]
+    lib.zk_comm_backend.restype = C.c_char_p
+    lib.zk_comm_stats.argtypes = [L.vp, u64p, u64p]
+    lib.zk_comm_all_reduce_sum_i64.argtypes = [L.vp, L.vp, L.sz]
+    lib.zk_comm_all_gather.argtypes = [L.vp, L.vp, L.vp, L.sz]
+    lib.zk_comm_broadcast.argtypes = [L.vp, L.vp, L.sz, C.c_int]
+    lib.zk_sharded_sumcheck_basic_prove.argtypes = [L.vp, L.vp, C.c_int, u64p, u64p, u64p]
+    lib.zk_sharded_sumcheck_gkr_prove.argtypes = [L.vp, vpp, L.sz, L.sz, u64p, L.vp, u64p, u64p, u64p]
+    lib.zk_sharded_mle_evaluate.argtypes = [L.vp, L.vp, u64p, L.sz, u64p]
+    lib.zk_sharded_msm_g1.argtypes = [L.vp, L.vp, L.vp, C.c_int, u64p, L.vp]
+    for name in ("zk_comm_unique_id", "zk_comm_init_rccl", "zk_comm_from_host_ops", "zk_comm_free", "zk_comm_stats",
+                 "zk_comm_all_reduce_sum_i64", "zk_comm_all_gather", "zk_comm_broadcast", "zk_sharded_sumcheck_basic_prove",
+                 "zk_sharded_sumcheck_gkr_prove", "zk_sharded_mle_evaluate", "zk_sharded_msm_g1"):
         getattr(lib, name).restype = C.c_int
     lib._sharded_declared = True
     return lib
@@ -75,7 +98,9 @@ def _declare_host():
 
 # ---- communication ---------------------------------------------------------------------------------
 class Comm:
-    """all-gather of small uint64 arrays over torch.distributed ("nccl" = RCCL on ROCm, or gloo)."""
+    """This rank's end of the exchange.  Python-level collectives on small uint64 arrays over torch.distributed ("nccl" =
+    RCCL on ROCm, or gloo) for the host-driven flow, and `native()`: the zk_comm the C-ABI provers run their collectives
+    on.  `bytes_received` counts the payload this rank received through the Python-level collectives."""
 
     def __init__(self, group=None, device=None):
         import torch.distributed as dist
@@ -84,45 +109,143 @@ class Comm:
         self.device = device
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bytes_received = 0
+        self._native = None
+        self._keep = None
+
+    def backend(self):
+        return self.dist.get_backend(self.group) if self.dist.is_initialized() else "none"
+
+    def _dev(self, t):
+        return t.to(self.device) if self.device is not None else t
 
     def all_gather(self, arr):
         import torch
         arr = np.ascontiguousarray(arr, np.uint64)
         if self.world == 1:
             return arr[None].copy()
-        t = torch.from_numpy(arr.view(np.int64).copy())
-        if self.device is not None:
-            t = t.to(self.device)
+        t = self._dev(torch.from_numpy(arr.view(np.int64).copy()))
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t, group=self.group)
+        self.bytes_received += (self.world - 1) * arr.nbytes
         return np.stack([o.cpu().numpy().view(np.uint64) for o in out])
 
-    def all_reduce_sum_(self, t):
-        """in-place element-wise integer sum of an int64 tensor (the widened-limb exchange of the device-resident rounds,
-        include/zkmle.h zk_rounds): RCCL all-reduce directly on the device tensor, no host synchronisation; a gloo group
-        (tests, rehearsal) stages through the host"""
-        if self.world == 1:
-            return t
-        backend = self.dist.get_backend(self.group)
-        if backend == "nccl" or not t.is_cuda:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        else:
-            h = t.cpu()
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
-            t.copy_(h)
-        return t
-
-    def all_gather_bytes(self, data):
-        """equal-length byte strings -> list of bytes, rank order"""
+    def gather_bytes(self, data, root=0):
+        """equal-length byte strings -> list of bytes in rank order on `root`, None elsewhere"""
         import torch
         if self.world == 1:
             return [bytes(data)]
-        t = torch.frombuffer(bytearray(data), dtype=torch.uint8)
-        if self.device is not None:
-            t = t.to(self.device)
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t, group=self.group)
+        t = self._dev(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+        out = [torch.empty_like(t) for _ in range(self.world)] if self.rank == root else None
+        self.dist.gather(t, out, dst=root, group=self.group)
+        if self.rank != root:
+            return None
+        self.bytes_received += (self.world - 1) * len(data)
         return [bytes(o.cpu().numpy().tobytes()) for o in out]
+
+    def broadcast_u64(self, arr, root=0):
+        """arr (uint64, same shape on every rank) <- root's arr"""
+        import torch
+        arr = np.ascontiguousarray(arr, np.uint64)
+        if self.world == 1:
+            return arr
+        t = self._dev(torch.from_numpy(arr.view(np.int64).copy()))
+        self.dist.broadcast(t, src=root, group=self.group)
+        if self.rank != root:
+            self.bytes_received += arr.nbytes
+        return t.cpu().numpy().view(np.uint64)
+
+    # ---- the communicator of the C-ABI provers (csrc/zkmle_sharded.hip) ----
+    def native(self):
+        """zk_comm handle: an RCCL communicator created by the library itself (ncclCommInitRank on this process's device,
+        the unique id travels over the torch process group) when the group's backend is "nccl"; a one-rank communicator
+        without any transport when there is no process group; exchange callbacks over the group (host memory; gloo)
+        otherwise."""
+        if self._native is not None:
+            return self._native
+        import torch
+        lib = _declare_host()
+        h = C.c_void_p()
+        backend = self.backend()
+        if backend == "none":
+            ops = HostOps()
+            L.check(lib.zk_comm_from_host_ops(C.byref(ops), 1, 0, C.byref(h)))
+        elif backend == "nccl":
+            uid = np.zeros(128, np.uint8)
+            if self.rank == 0:
+                L.check(lib.zk_comm_unique_id(L.p8(uid)))
+            if self.world > 1:
+                t = torch.from_numpy(uid).to(self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device()))
+                self.dist.broadcast(t, src=0, group=self.group)
+                uid = t.cpu().numpy()
+            L.check(lib.zk_comm_init_rccl(L.p8(np.ascontiguousarray(uid)), self.world, self.rank, C.byref(h)))
+        else:
+            dist, group, world, rank = self.dist, self.group, self.world, self.rank
+
+            def view(ptr, nbytes):
+                return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (nbytes,)))
+
+            def all_reduce(ctx, buf, count):
+                try:
+                    t = torch.from_numpy(np.ctypeslib.as_array(buf, (count,)))
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    return 0
+                except Exception:                                  # noqa: BLE001  (must not unwind through C)
+                    return 1
+
+            def all_gather(ctx, send, recv, nbytes):
+                try:
+                    out = view(recv, nbytes * world)
+                    dist.all_gather(list(out.view(world, nbytes).unbind(0)), view(send, nbytes).clone(), group=group)
+                    return 0
+                except Exception:                                  # noqa: BLE001
+                    return 1
+
+            def gather(ctx, send, recv, nbytes, root):
+                try:
+                    outs = list(view(recv, nbytes * world).view(world, nbytes).unbind(0)) if rank == root else None
+                    dist.gather(view(send, nbytes).clone(), outs, dst=root, group=group)
+                    return 0
+                except Exception:                                  # noqa: BLE001
+                    return 1
+
+            def broadcast(ctx, buf, nbytes, root):
+                try:
+                    dist.broadcast(view(buf, nbytes), src=root, group=group)
+                    return 0
+                except Exception:                                  # noqa: BLE001
+                    return 1
+
+            ops = HostOps()
+            ops.ctx = None
+            ops.all_reduce_sum_i64 = HostOps._fields_[1][1](all_reduce)
+            ops.all_gather = HostOps._fields_[2][1](all_gather)
+            ops.gather = HostOps._fields_[3][1](gather)
+            ops.broadcast = HostOps._fields_[4][1](broadcast)
+            self._keep = ops                                        # the callbacks live as long as the communicator
+            L.check(lib.zk_comm_from_host_ops(C.byref(ops), world, rank, C.byref(h)))
+        self._native = h
+        return h
+
+    def native_backend(self):
+        return _declare_host().zk_comm_backend(self.native()).decode()
+
+    def native_stats(self):
+        """(payload bytes received, collectives issued) by the C-ABI provers on this rank"""
+        rx, n = C.c_uint64(0), C.c_uint64(0)
+        L.check(_declare_host().zk_comm_stats(self.native(), C.byref(rx), C.byref(n)))
+        return int(rx.value), int(n.value)
+
+    def close(self):
+        if self._native is not None and L._lib is not None:
+            L.lib().zk_comm_free(self._native)
+        self._native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                          # noqa: BLE001
+            pass
 
 
 # ---- per-shard engines -----------------------------------------------------------------------------
@@ -165,6 +288,22 @@ def shard_of(global_table, rank, world):
     return np.ascontiguousarray(np.asarray(global_table)[rank::world])
 
 
+def absorb_sharded_table(comm, t, local_bytes, esz, chunk_elems=1 << 15):
+    """transcript.append(convert_to_bytes(table)) (prover.rs:38-39) for a low-bit-sharded table: the sponge is sequential,
+    so rank 0 alone hashes -- the ranks send their canonical bytes to rank 0 chunk by chunk (gather), rank 0 interleaves a
+    chunk into global index order (element j of rank r is global j * G + r) and absorbs it, and the 208-byte sponge state
+    is broadcast.  Non-root ranks receive 208 bytes."""
+    G = comm.world
+    n = len(local_bytes) // esz
+    for off in range(0, n, chunk_elems):
+        parts = comm.gather_bytes(local_bytes[off * esz:(off + chunk_elems) * esz], 0)
+        if parts is not None:
+            views = [np.frombuffer(p, np.uint8).reshape(-1, esz) for p in parts]
+            t.append(np.stack(views, axis=1).tobytes())
+    if G > 1:
+        t.import_state(comm.broadcast_u64(t.export_state(), 0))
+
+
 # ---- sharded basic sumcheck (prover.rs:35-71) -------------------------------------------------------
 def sumcheck_basic_prove(comm, shard, absorb_table=True):
     """-> (claimed_sum, round_polys (n, 2, limbs), challenges (n, limbs)); identical on every rank and
@@ -175,10 +314,8 @@ def sumcheck_basic_prove(comm, shard, absorb_table=True):
     assert G & (G - 1) == 0, "world size must be a power of two"
     t = Transcript()
     esz = 8 * limbs(field)
-    if absorb_table:                                            # prover.rs:38-39, global index order
-        parts = comm.all_gather_bytes(shard.to_bytes())
-        views = [np.frombuffer(p, np.uint8).reshape(-1, esz) for p in parts]
-        t.append(np.stack(views, axis=1).tobytes())             # element j of rank r is global j * G + r
+    if absorb_table:
+        absorb_sharded_table(comm, t, shard.to_bytes(), esz)
     rounds, chal = [], []
     cur = shard
     replicated = False
@@ -326,117 +463,58 @@ def msm(comm, local_msm):
     return g1_sum(comm.all_gather(local_msm()))
 
 
-# ---- device-resident sharded provers: no host round trip per round (include/zkmle.h, zk_rounds) -----------------------
-class DeviceRounds:
-    """zk_rounds handle + the int64 limb buffer the ranks all-reduce.  One per sumcheck."""
-
-    def __init__(self, field, mode, nprod, nfac, nrounds, transcript, device=None):
-        import torch
-        lib = _declare_host()
-        self.field, self.mode, self.nprod, self.nfac, self.nrounds = field, mode, nprod, nfac, nrounds
-        self._t = transcript
-        h = C.c_void_p()
-        L.check(lib.zk_rounds_new(field, mode, nprod, nfac, nrounds, transcript._h, C.byref(h)))
-        self._h = h
-        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.limbs = torch.zeros(int(lib.zk_rounds_limbs_len(h)), dtype=torch.int64, device=dev)
-
-    def __del__(self):
-        if getattr(self, "_h", None) is not None and L._lib is not None:
-            L.lib().zk_rounds_free(self._h)
-            self._h = None
-
-    @staticmethod
-    def _arr(tabs):
-        flat = [p._h for p in tabs]
-        return (C.c_void_p * len(flat))(*flat)
-
-    def evals(self, tabs):
-        L.check(L.lib().zk_rounds_evals(self._h, self._arr(tabs), C.c_void_p(self.limbs.data_ptr())))
-
-    def fold_evals(self, tabs):
-        half = len(tabs[0]) // 2
-        outs = [MultilinearPolynomial.alloc(self.field, half) for _ in tabs]
-        L.check(L.lib().zk_rounds_fold_evals(self._h, self._arr(tabs), self._arr(outs), C.c_void_p(self.limbs.data_ptr())))
-        return outs
-
-    def absorb(self):
-        L.check(L.lib().zk_rounds_absorb(self._h, C.c_void_p(self.limbs.data_ptr())))
-
-    def tail(self, tabs):
-        L.check(L.lib().zk_rounds_tail(self._h, self._arr(tabs)))
-
-    def collect(self, want_final):
-        n = limbs(self.field)
-        npts = self.nfac + 1
-        claimed = np.zeros(n, np.uint64)
-        msgs = np.zeros((self.nrounds, npts, n), np.uint64)
-        chal = np.zeros((self.nrounds, n), np.uint64)
-        fin = np.zeros((self.nprod * self.nfac, n), np.uint64)
-        L.check(L.lib().zk_rounds_collect(self._h, self._t._h, L.p64(claimed), L.p64(msgs), L.p64(chal), L.p64(fin) if want_final else None))
-        return claimed, msgs, chal, fin
-
-
-def _device_rounds(comm, field, mode, tabs, nprod, nfac, transcript):
-    """shared driver: tabs = this rank's local tables (MultilinearPolynomial handles, low-bit shards).
-    -> (claimed, messages, challenges, final values (ntab, limbs))"""
-    G = comm.world
-    assert G & (G - 1) == 0, "world size must be a power of two"
-    nloc = len(tabs[0]).bit_length() - 1
-    g = G.bit_length() - 1
-    nrounds = nloc + g
-    dr = DeviceRounds(field, mode, nprod, nfac, nrounds, transcript, comm.device)
-    cur = tabs
-    if nloc >= 1:
-        dr.evals(cur)
-        comm.all_reduce_sum_(dr.limbs)                          # the round's only exchange, on the device
-        dr.absorb()
-        while len(cur[0]) >= 4:
-            cur = dr.fold_evals(cur)
-            comm.all_reduce_sum_(dr.limbs)
-            dr.absorb()
-        cur = dr.fold_evals(cur)                                # 2 entries -> 1
-    if g == 0:
-        claimed, msgs, chal, _ = dr.collect(False)
-        fin = np.stack([p.evaluated_values[0] for p in cur])
-        return claimed, msgs, chal, fin
-    # one entry per rank and table left: gather them (global index = rank) and finish replicated, in one launch
-    mine = np.stack([p.evaluated_values[0] for p in cur])       # (ntab, limbs)
-    allv = comm.all_gather(mine)                                # (G, ntab, limbs)
-    rep = [MultilinearPolynomial(field, np.ascontiguousarray(allv[:, k, :])) for k in range(len(cur))]
-    dr.evals(rep)                                               # already global: no all-reduce
-    dr.absorb()
-    dr.tail(rep)
-    return dr.collect(True)
+# ---- the product path: one C-ABI call per prover (include/zkmle.h zk_sharded_*, csrc/zkmle_sharded.hip) -------------------
+def _tab_arr(tabs):
+    return (C.c_void_p * len(tabs))(*[p._h for p in tabs])
 
 
 def sumcheck_gkr_prove_device(comm, shard, claimed_sum, transcript):
-    """sumcheck_gkr_prove with the transcript on the device: same bytes, one all-reduce per local round, one host
-    synchronisation at the gather and one at the end.  -> (coefficient rows, challenges, final table values)"""
+    """sumcheck_gkr_protocol::prove (:24-67) on this rank's low-bit shards: per local round one fused kernel, ONE all-reduce
+    of 27 int64 words on the prover's stream (RCCL) and the transcript kernel; the <= 2048 last global entries are gathered
+    and finished replicated in one launch.  Same bytes as the single-device prover on every rank.
+    -> (coefficient rows, challenges, final table values)"""
+    lib = _declare_host()
     field = shard.field
-    transcript.append(fe_to_bytes_be(field, claimed_sum))       # sumcheck_gkr_protocol.rs:35
     flat = [p for prod in shard.tables for p in prod]
-    if len(flat[0]) * comm.world == 1:
-        return (np.zeros((0, shard.nfac + 1, limbs(field)), np.uint64), np.zeros((0, limbs(field)), np.uint64),
-                np.stack([p.evaluated_values[0] for p in flat]))
-    _, msgs, chal, fin = _device_rounds(comm, field, 1, flat, shard.nprod, shard.nfac, transcript)
-    return msgs, chal, fin
+    n = limbs(field)
+    nrounds = (len(flat[0]) * comm.world).bit_length() - 1
+    co = np.zeros((nrounds, shard.nfac + 1, n), np.uint64)
+    ch = np.zeros((nrounds, n), np.uint64)
+    fin = np.zeros((len(flat), n), np.uint64)
+    L.check(lib.zk_sharded_sumcheck_gkr_prove(comm.native(), _tab_arr(flat), shard.nprod, shard.nfac,
+                                              L.p64(np.ascontiguousarray(claimed_sum, np.uint64)), transcript._h,
+                                              L.p64(co), L.p64(ch), L.p64(fin)))
+    return co, ch, fin
 
 
 def sumcheck_basic_prove_device(comm, shard, absorb_table=True):
-    """sumcheck_basic_prove with device-resident rounds.  -> (claimed_sum, round_polys, challenges)"""
-    _declare_host()
+    """Prover::prove (prover.rs:35-71) of the sharded table through the C ABI.  -> (claimed_sum, round_polys, challenges)"""
+    lib = _declare_host()
     field = shard.field
-    G = comm.world
-    t = Transcript()
-    esz = 8 * limbs(field)
-    if absorb_table:                                            # prover.rs:38-39, global index order
-        parts = comm.all_gather_bytes(shard.to_bytes())
-        views = [np.frombuffer(p, np.uint8).reshape(-1, esz) for p in parts]
-        t.append(np.stack(views, axis=1).tobytes())
-    if len(shard) * G == 1:
-        claimed = shard.download()[0]
-        t.append(fe_to_bytes_be(field, claimed))
-        return claimed, np.zeros((0, 2, limbs(field)), np.uint64), np.zeros((0, limbs(field)), np.uint64)
-    claimed, msgs, chal, _ = _device_rounds(comm, field, 0, [shard.poly], 1, 1, t)
-    return claimed, msgs, chal
+    n = limbs(field)
+    nrounds = (len(shard) * comm.world).bit_length() - 1
+    claimed = np.zeros(n, np.uint64)
+    rp = np.zeros((nrounds, 2, n), np.uint64)
+    ch = np.zeros((nrounds, n), np.uint64)
+    L.check(lib.zk_sharded_sumcheck_basic_prove(comm.native(), shard.poly._h, 1 if absorb_table else 0, L.p64(claimed),
+                                                L.p64(rp), L.p64(ch)))
+    return claimed, rp, ch
+
+
+def mle_evaluate(comm, poly, values):
+    """MultilinearPolynomial::evaluate (evaluation_form.rs:21-33) of the sharded table at log2(local) + log2(G) points"""
+    lib = _declare_host()
+    v = np.ascontiguousarray(values, np.uint64).reshape(-1, limbs(poly.field))
+    out = np.zeros(limbs(poly.field), np.uint64)
+    L.check(lib.zk_sharded_mle_evaluate(comm.native(), poly._h, L.p64(v), v.shape[0], L.p64(out)))
+    return out
+
+
+def msm_device(comm, scalars, bases, window_bits=0, with_stats=False):
+    """commit_to_polynomial (multilinear_kzg.rs:37-42) with the terms sliced over the ranks, through the C ABI"""
+    from .kzg import MsmStats
+    lib = _declare_host()
+    out = np.zeros(12, np.uint64)
+    st = MsmStats()
+    L.check(lib.zk_sharded_msm_g1(comm.native(), scalars._h, bases._h, window_bits, L.p64(out), C.byref(st)))
+    return (out, st.as_dict()) if with_stats else out

@@ -27,6 +27,7 @@ def _decl():
         "zk_transcript_new": [C.POINTER(vp)], "zk_transcript_free": [vp],
         "zk_transcript_append": [vp, u8p, sz], "zk_transcript_sample": [vp, u8p],
         "zk_transcript_challenge": [vp, C.c_int, u64p], "zk_keccak256": [u8p, sz, u8p],
+        "zk_transcript_export_state": [vp, u64p, C.POINTER(C.c_uint32)], "zk_transcript_import_state": [vp, u64p, C.c_uint32],
         "zk_uni_evaluate": [C.c_int, u64p, sz, u64p, u64p],
         "zk_uni_lagrange_interpolate": [C.c_int, u64p, u64p, sz, u64p],
         "zk_sumcheck_basic_prove": [vp, u64p, u64p, u64p],
@@ -95,6 +96,18 @@ class Transcript:
         out = np.zeros(limbs(field), np.uint64)
         L.check(_decl().zk_transcript_challenge(self._h, field, L.p64(out)))
         return out
+
+    def export_state(self):
+        """the running sponge: 26 uint64 words = 25 Keccak lanes + the fill of the open block (208 bytes)"""
+        st = np.zeros(26, np.uint64)
+        fill = C.c_uint32(0)
+        L.check(_decl().zk_transcript_export_state(self._h, L.p64(st), C.byref(fill)))
+        st[25] = fill.value
+        return st
+
+    def import_state(self, st):
+        st = np.ascontiguousarray(st, np.uint64)
+        L.check(_decl().zk_transcript_import_state(self._h, L.p64(st), int(st[25])))
 
 
 def lagrange_interpolate(field, xs, ys):
