@@ -381,9 +381,10 @@ def msm_leg(zk, comm, args, rank, world):
     return res
 
 
-# v_mad_u64_u32 instructions per lane of one mixed addition of msm_bucket_sum_kernel (csrc/g1u.cuh g1u_madd, 14 x 29-bit limbs of
-# Fq381): counted in DESIGN.md section 4 from the kernel's ISA.
-MADS_PER_MIXED_ADD = 3724
+# v_mad_u64_u32 per lane of one mixed addition of msm_bucket_sum_kernel (csrc/g1u.cuh g1u_madd on 14 x 29-bit limbs of Fq381):
+# 6 products (392) + 2 squarings (301) + 1 dual product with one reduction (588).  Source-level count = the ISA's common path
+# (tools/count_mads.py, profiles/r2/msm_mad_count.txt).
+MADS_PER_MIXED_ADD = 6 * 392 + 2 * 301 + 588
 
 
 def msm_roofline(st):

@@ -172,6 +172,9 @@ int zk_sumcheck_basic_verify(const zk_table *table, const uint64_t *claimed_sum,
 int zk_sumpoly_evaluate(const zk_table *const *tables, size_t nprod, size_t nfac,
                         const uint64_t *values, size_t nvalues, uint64_t *out);    /* sum_polynomial.rs:30 */
 int zk_sumpoly_reduce(const zk_table *const *tables, size_t nprod, size_t nfac, zk_table *out); /* :57 add_polynomials_element_wise */
+/* ProductPolynomial::multiply_polynomials_element_wise (product_polynomial.rs:58-73): out[i] = prod_f tables[f][i]; nfac >= 2
+ * (the reference asserts "more than one polynomial required for mul operation") */
+int zk_prodpoly_reduce(const zk_table *const *tables, size_t nfac, zk_table *out);
 /* generate_round_univariate sumcheck_gkr_protocol.rs:113-143 ; out: nfac+1 evaluations at 0..nfac */
 int zk_sumpoly_round_evals(const zk_table *const *tables, size_t nprod, size_t nfac, uint64_t *out);
 /* one fused prover round on caller-managed tables: fold every table of `in` by `value` into `out`

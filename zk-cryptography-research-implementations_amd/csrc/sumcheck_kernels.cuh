@@ -258,8 +258,8 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
 // tables of 4q entries in, 2q out; lane i folds outputs i and i+q of every table, then uses them
 // as the (lo, hi) pair of the NEXT round.
 template <class F, int NFAC>
-__global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials,
-                                                                  const void *__restrict__ rp = nullptr, int skip1 = 0) {
+__device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs, int nprod, size_t q, const Fe<F> &r, void *__restrict__ partials,
+                                                      const void *__restrict__ rp, int skip1) {
     if constexpr (NFAC == 2 && LazyProducts<F>::value) {
         __shared__ ProdWide<F> shp[3 * kBlock / 64];
         ProdAcc<F> pacc[3] = {prod_zero<F>(), prod_zero<F>(), prod_zero<F>()};
@@ -315,6 +315,18 @@ __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables 
         }
     }
     write_partials<F, NFAC>(acc, sh, partials);
+}
+template <class F, int NFAC>
+__global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials,
+                                                                  const void *__restrict__ rp = nullptr, int skip1 = 0) {
+    fold_round_evals_body<F, NFAC>(tabs, nprod, q, r, partials, rp, skip1);
+}
+// the same body compiled for 4 waves per SIMD (<= 128 VGPRs): experiment ZK_FRE_VARIANT=1 (profiles/r2/gkr_round_variants.md)
+template <class F, int NFAC>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+fold_round_evals_occ4_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials, const void *__restrict__ rp = nullptr,
+                             int skip1 = 0) {
+    fold_round_evals_body<F, NFAC>(tabs, nprod, q, r, partials, rp, skip1);
 }
 
 // The same round for SHORT tables of products of two factors.  Below ~2^15 pair indices the launch above does not fill the

@@ -283,7 +283,9 @@ template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int np
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
+    static const int variant = [] { const char *e = getenv("ZK_FRE_VARIANT"); return e ? atoi(e) : 0; }();
     if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
+    else if (nfac == 2 && variant == 1) fold_round_evals_occ4_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
     else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
     else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
     ZK_HIP(hipGetLastError());
@@ -688,6 +690,19 @@ int zk_sumpoly_reduce(const zk_table *const *tables, size_t nprod, size_t nfac, 
     for (size_t k = 0; k < nprod * nfac; k++) tabs.in[k] = tables[k]->dptr;
     size_t len = tables[0]->len;
     ZK_DISPATCH_FIELD(tables[0]->field, (sumpoly_reduce_kernel<F><<<grid_for(len), kBlock, 0, cur_stream()>>>(tabs, (int)nprod, (int)nfac, len, out->dptr)));
+    ZK_HIP(hipGetLastError());
+    out->len = len;
+    return ZK_OK;
+}
+int zk_prodpoly_reduce(const zk_table *const *tables, size_t nfac, zk_table *out) {
+    ZK_TRY(check_sumpoly(tables, 1, nfac));
+    if (!out || out->field != tables[0]->field || out->len < tables[0]->len) return ZK_E_ARG;
+    if (nfac < 2) return ZK_E_NEED_TWO;                  // product_polynomial.rs:59-62
+    ZK_TRY(require_device());
+    SumPolyTables tabs{};
+    for (size_t k = 0; k < nfac; k++) tabs.in[k] = tables[k]->dptr;
+    size_t len = tables[0]->len;
+    ZK_DISPATCH_FIELD(tables[0]->field, (sumpoly_reduce_kernel<F><<<grid_for(len), kBlock, 0, cur_stream()>>>(tabs, 1, (int)nfac, len, out->dptr)));
     ZK_HIP(hipGetLastError());
     out->len = len;
     return ZK_OK;

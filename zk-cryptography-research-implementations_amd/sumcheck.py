@@ -34,6 +34,7 @@ def _decl():
         "zk_sumcheck_basic_verify": [vp, u64p, u64p, sz, C.POINTER(C.c_int)],
         "zk_sumpoly_evaluate": [C.POINTER(vp), sz, sz, u64p, sz, u64p],
         "zk_sumpoly_reduce": [C.POINTER(vp), sz, sz, vp],
+        "zk_prodpoly_reduce": [C.POINTER(vp), sz, vp],
         "zk_sumpoly_round_evals": [C.POINTER(vp), sz, sz, u64p],
         "zk_sumcheck_gkr_prove": [C.POINTER(vp), sz, sz, u64p, vp, u64p, u64p],
         "zk_sumcheck_gkr_verify": [C.c_int, u64p, u64p, sz, sz, vp, u64p, u64p, C.POINTER(C.c_int)],
@@ -148,9 +149,10 @@ class ProductPolynomial:
     def multiply_polynomials_element_wise(self):                        # :58-73
         if len(self.polynomials) < 2:
             raise L.ReferencePanic(L.ZK_E_NEED_TWO, "more than one polynomial required for mul operation")
-        f = self.polynomials[0].field
-        zero = MultilinearPolynomial(f, np.zeros((len(self.polynomials[0]), limbs(f)), np.uint64))
-        return SumPolynomial._reduce([self.polynomials, [zero] * len(self.polynomials)])
+        out = MultilinearPolynomial.alloc(self.polynomials[0].field, len(self.polynomials[0]))
+        arr = (C.c_void_p * len(self.polynomials))(*[p._h for p in self.polynomials])
+        L.check(_decl().zk_prodpoly_reduce(arr, len(self.polynomials), out._h))
+        return out
 
 
 class SumPolynomial:
