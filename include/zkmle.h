@@ -192,6 +192,13 @@ int zk_sumcheck_gkr_prove(const zk_table *const *tables, size_t nprod, size_t nf
  * the nprod*nfac one-entry tables left after the last fold. */
 int zk_sumcheck_gkr_rounds(const zk_table *const *tables, size_t nprod, size_t nfac, zk_transcript *t,
                            uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values);
+/* the same rounds where the SECOND factor of some two-factor products is a constant: tables[p * 2 + 1] == NULL means
+ * "const_factors[p] at every index" (nfac must be 2, const_factors: nprod elements).  A product with a constant factor is a
+ * linear term sum_i c X(i); its table is never materialised, streamed or folded, and the proof is the one the rounds above give
+ * with that table filled with the constant (tests/test_gpu_sumcheck.py).  The sparse GKR prover's phases W H1 + H0 * 1 and
+ * C W + A * u run through it with three tables instead of four. */
+int zk_sumcheck_gkr_rounds_cf(const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *const_factors,
+                              zk_transcript *t, uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values);
 /* verify :69-105 (host only: O(rounds) field operations) */
 int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_t *round_coeffs,
                            size_t nrounds, size_t ncoef, zk_transcript *t, uint64_t *challenges,

@@ -331,3 +331,33 @@ def test_full_size_provers_size_independent_properties(zk):
     co[3, 1, 0] ^= np.uint64(1)
     bad = zk.sumcheck.SumcheckProverProof(res.claimed_sum, co, res.random_challenges)
     assert not zk.sumcheck.verify(bad, zk.Transcript(), field).is_proof_valid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,logn,consts", [(0, 1, (1, 1)), (0, 3, (0, 1)), (0, 7, (1, 1)), (0, 11, (0, 1)), (0, 12, (1, 0)), (0, 14, (0, 1)),
+                                               (0, 17, (0, 1)), (0, 18, (1, 1)), (2, 13, (0, 1)), (1, 9, (0, 1)), (1, 13, (1, 0)), (3, 16, (0, 1))])
+def test_gkr_rounds_with_constant_factors_vs_oracle(zk, field, logn, consts):
+    """zk_sumcheck_gkr_rounds_cf: a product whose second factor is a constant never materialises that table (the sparse GKR prover's
+    W H1 + H0 * 1 and C W + A * u).  Coefficients, challenges, final values and the sponge must equal the oracle's proof of the
+    same SumPolynomial with the constant tables written out -- every kernel that takes the shortcut: tail (<= 2^11 entries, all
+    three lane splits), split rounds, large fused rounds, 4- and 6-limb fields."""
+    n = 1 << logn
+    MP = zk.MultilinearPolynomial
+    cvals = rand_table(zk, field, 2, 4000 + logn)
+    cvals[1] = O.from_ints(field, [1])[0]
+    full = np.stack([np.stack([MP.random(field, n, 3000 + 10 * logn + 2 * p + f).evaluated_values for f in range(2)]) for p in range(2)])
+    for p in range(2):
+        if consts[p]:
+            full[p, 1] = cvals[p]
+    tables = [(MP(field, full[p, 0]), None if consts[p] else MP(field, full[p, 1])) for p in range(2)]
+    claimed = O.vec_sum(field, O.sumpoly_reduce(field, full))
+    t_gpu, t_cpu = zk.Transcript(), O.Transcript()
+    t_gpu.append(b"phase")
+    t_cpu.append(b"phase")
+    t_gpu.append(O.fe_to_bytes_be(field, claimed))                 # sumcheck_gkr_protocol.rs:35 (the rounds entry leaves it to the caller)
+    co, ch, fin = zk.sumcheck.gkr_rounds_const_factors(field, tables, cvals, t_gpu)
+    want_co, want_ch = O.sumcheck_gkr_prove(field, full, claimed, t_cpu)
+    assert np.array_equal(co, want_co) and np.array_equal(ch, want_ch)
+    assert t_gpu.sample_random_challenge() == t_cpu.sample_random_challenge()
+    want_fin = np.stack([O.evaluate(field, full[p, f], want_ch) for p in range(2) for f in range(2)])
+    assert np.array_equal(fin, want_fin)

@@ -418,6 +418,7 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                     Fe<F> lo[NFAC], hi[NFAC];
 #pragma unroll
                     for (int f = 0; f < NFAC; f++) {
+                        if (NFAC == 2 && f == 1 && a.tabs.in[p * NFAC + 1] == nullptr) { lo[1] = hi[1] = const_factor<F>(a.tabs, p); continue; }
                         const void *src = prev ? (const void *)(prev + (size_t)(p * NFAC + f) * cl * esz) : a.tabs.in[p * NFAC + f];
                         void *out = dst + (size_t)(p * NFAC + f) * ol * esz;
                         Fe<F> a0 = fe_load<F>(src, tid), a1 = fe_load<F>(src, tid + q);
@@ -440,6 +441,7 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
 #pragma unroll
                     for (int f = 0; f < NFAC; f++) {
                         const int k = (int)grp * NFAC + f;
+                        if (f == 1 && a.tabs.in[k] == nullptr) { lo[1] = hi[1] = const_factor<F>(a.tabs, (int)grp); continue; }
                         const void *src = prev ? (const void *)(prev + (size_t)k * cl * esz) : a.tabs.in[k];
                         void *out = dst + (size_t)k * ol * esz;
                         Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
@@ -456,14 +458,18 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                 const bool act = grp < (unsigned)a.ntab;
                 Fe<F> lo = fe_zero<F>(), hi = fe_zero<F>();
                 if (act) {
-                    const void *src = prev ? (const void *)(prev + (size_t)grp * cl * esz) : a.tabs.in[grp];
-                    void *out = dst + (size_t)grp * ol * esz;
-                    Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
-                    Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
-                    lo = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
-                    hi = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
-                    fe_store<F>(out, i, lo);
-                    fe_store<F>(out, i + q, hi);
+                    if (a.tabs.in[grp] == nullptr) {
+                        lo = hi = const_factor<F>(a.tabs, (int)(grp >> 1));
+                    } else {
+                        const void *src = prev ? (const void *)(prev + (size_t)grp * cl * esz) : a.tabs.in[grp];
+                        void *out = dst + (size_t)grp * ol * esz;
+                        Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
+                        Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
+                        lo = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
+                        hi = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
+                        fe_store<F>(out, i, lo);
+                        fe_store<F>(out, i + q, hi);
+                    }
                     exch[2 * (grp * (unsigned)q + i)] = lo;
                     exch[2 * (grp * (unsigned)q + i) + 1] = hi;
                 }
@@ -493,9 +499,14 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
     }
     if (cl == 2 && (int)tid < a.ntab) {                      // last round: 2 entries -> 1 (nothing left to sum)
         const Multiplier<F> mr(r);
-        const void *src = prev ? (const void *)(prev + (size_t)tid * cl * esz) : a.tabs.in[tid];
-        Fe<F> y1 = fe_load<F>(src, 0), y2 = fe_load<F>(src, 1);
-        Fe<F> v = fe_add<F>(y1, mr.times(fe_sub<F>(y2, y1)));
+        Fe<F> v;
+        if (a.tabs.in[tid] == nullptr) {
+            v = const_factor<F>(a.tabs, (int)(tid / NFAC));
+        } else {
+            const void *src = prev ? (const void *)(prev + (size_t)tid * cl * esz) : a.tabs.in[tid];
+            Fe<F> y1 = fe_load<F>(src, 0), y2 = fe_load<F>(src, 1);
+            v = fe_add<F>(y1, mr.times(fe_sub<F>(y2, y1)));
+        }
         fe_store<F>((char *)a.buf[j & 1] + (size_t)tid * esz, 0, v);
         if (a.fin_slot != ~(size_t)0) fe_store<F>(a.ctx.proof, a.fin_slot + tid, v);
     }

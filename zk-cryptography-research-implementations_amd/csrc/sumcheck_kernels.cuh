@@ -21,9 +21,19 @@ constexpr int kMaxProducts = 8;
 constexpr int kMaxFactors = 3;
 
 struct SumPolyTables {
-    const void *in[kMaxProducts * kMaxFactors];   // [p * nfac + f]
+    const void *in[kMaxProducts * kMaxFactors];   // [p * nfac + f]; nullptr = the CONSTANT factor cval[p] (second factor of a two-factor product)
     void *out[kMaxProducts * kMaxFactors];
+    uint32_t cval[kMaxProducts][12];               // stored (Montgomery) form
 };
+// A product whose second factor is a constant c is a linear term: sum_i c X(i).  Its table is never materialised, loaded, folded or
+// stored (a constant folds to itself); the evaluation products use c directly.  The sparse GKR prover's phases are
+// W H1 + H0 * 1 and C W + A * u (zkmle_gkr_sparse.hip): three streamed tables instead of four.
+template <class F> __device__ __forceinline__ Fe<F> const_factor(const SumPolyTables &t, int p) {
+    Fe<F> e;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) e.l[i] = t.cval[p][i];
+    return e;
+}
 
 // accumulate the NFAC+1 evaluation terms of one product at one pair index
 template <class F, int NFAC>
@@ -222,6 +232,7 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
                 Fe<F> lo[2], hi[2];
 #pragma unroll
                 for (int f = 0; f < 2; f++) {
+                    if (f == 1 && tabs.in[p * 2 + 1] == nullptr) { lo[1] = hi[1] = const_factor<F>(tabs, p); continue; }
                     lo[f] = fe_load<F>(tabs.in[p * 2 + f], i);
                     hi[f] = fe_load<F>(tabs.in[p * 2 + f], i + half);
                 }
@@ -246,6 +257,7 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
             Fe<F> lo[NFAC], hi[NFAC];
 #pragma unroll
             for (int f = 0; f < NFAC; f++) {
+                if (NFAC == 2 && f == 1 && tabs.in[p * NFAC + 1] == nullptr) { lo[1] = hi[1] = const_factor<F>(tabs, p); continue; }
                 lo[f] = fe_load<F>(tabs.in[p * NFAC + f], i);
                 hi[f] = fe_load<F>(tabs.in[p * NFAC + f], i + half);
             }
@@ -273,6 +285,7 @@ __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs,
                 for (int f = 0; f < 2; f++) {
                     const void *src = tabs.in[p * 2 + f];
                     void *dst = tabs.out[p * 2 + f];
+                    if (f == 1 && src == nullptr) { lo[1] = hi[1] = const_factor<F>(tabs, p); continue; }
                     Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
                     Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
                     lo[f] = fe_add<F>(a0, pmr.times(fe_sub<F>(b0, a0)));
@@ -304,6 +317,7 @@ __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs,
             for (int f = 0; f < NFAC; f++) {
                 const void *src = tabs.in[p * NFAC + f];
                 void *dst = tabs.out[p * NFAC + f];
+                if (NFAC == 2 && f == 1 && src == nullptr) { lo[1] = hi[1] = const_factor<F>(tabs, p); continue; }
                 Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
                 Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
                 lo[f] = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
@@ -321,14 +335,6 @@ __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables 
                                                                   const void *__restrict__ rp = nullptr, int skip1 = 0) {
     fold_round_evals_body<F, NFAC>(tabs, nprod, q, r, partials, rp, skip1);
 }
-// the same body compiled for 4 waves per SIMD (<= 128 VGPRs): experiment ZK_FRE_VARIANT=1 (profiles/r2/gkr_round_variants.md)
-template <class F, int NFAC>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
-fold_round_evals_occ4_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials, const void *__restrict__ rp = nullptr,
-                             int skip1 = 0) {
-    fold_round_evals_body<F, NFAC>(tabs, nprod, q, r, partials, rp, skip1);
-}
-
 // The same round for SHORT tables of products of two factors.  Below ~2^15 pair indices the launch above does not fill the
 // device and lasts as long as one lane's chain of products (14 for two products); here a wave takes ONE table for 64 consecutive
 // pair indices (2 fold products per lane), the factors of a product meet in LDS, and the even wave of a product evaluates the
@@ -345,12 +351,17 @@ __global__ void __launch_bounds__(512) fold_round_evals_split_kernel(SumPolyTabl
     const Multiplier<F> mr(challenge_arg<F>(r, rp));
     const void *src = tabs.in[k];
     void *dst = tabs.out[k];
-    Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
-    Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
-    const Fe<F> lo = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
-    const Fe<F> hi = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
-    fe_store<F>(dst, i, lo);
-    fe_store<F>(dst, i + q, hi);
+    Fe<F> lo, hi;
+    if (src == nullptr) {                                       // constant factor (wave-uniform): nothing to load, fold or store
+        lo = hi = const_factor<F>(tabs, (int)(k >> 1));
+    } else {
+        Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
+        Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
+        lo = fe_add<F>(a0, mr.times(fe_sub<F>(b0, a0)));
+        hi = fe_add<F>(a1, mr.times(fe_sub<F>(b1, a1)));
+        fe_store<F>(dst, i, lo);
+        fe_store<F>(dst, i + q, hi);
+    }
     exch[2 * (k * 64 + lane)] = lo;
     exch[2 * (k * 64 + lane) + 1] = hi;
     __syncthreads();

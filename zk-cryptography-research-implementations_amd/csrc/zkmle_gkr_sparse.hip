@@ -44,10 +44,6 @@ int alloc_table(int field, size_t len, TablePtr &out) {
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------
-template <class F> __global__ void fill_one_kernel(void *out, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) fe_store<F>(out, i, fe_one<F>());
-}
 struct GateArrays {
     const uint32_t *out, *left, *right, *op;      // SoA on the device
 };
@@ -81,11 +77,12 @@ template <class F> __global__ void phase1_tables_kernel(const uint32_t *__restri
     fe_store<F>(H1, b, h1);
     fe_store<F>(H0, b, h0);
 }
-// one lane per right index c (gates grouped by right index)
+// one lane per right index c (gates grouped by right index): A(c) = sum of the add gates' w eqL[left], M(c) the same over the mul gates;
+// stored: C = A + u M and A, so that phase 2 is the sumcheck of C(c) W(c) + u A(c)  (= A (u + W) + M u W)
 template <class F> __global__ void phase2_tables_kernel(const uint32_t *__restrict__ start, size_t nc, const void *__restrict__ w,
                                                         const uint32_t *__restrict__ order, const uint32_t *__restrict__ left_r,
                                                         const uint32_t *__restrict__ op_r,
-                                                        const void *__restrict__ eqL, void *__restrict__ A, void *__restrict__ M) {
+                                                        const void *__restrict__ eqL, Fe<F> u, void *__restrict__ Cc, void *__restrict__ A) {
     size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nc) return;
     Fe<F> a = fe_zero<F>(), m = fe_zero<F>();
@@ -93,15 +90,8 @@ template <class F> __global__ void phase2_tables_kernel(const uint32_t *__restri
         Fe<F> t = fe_mul<F>(fe_load<F>(w, order[e]), fe_load<F>(eqL, left_r[e]));
         if (op_r[e] == 0) a = fe_add<F>(a, t); else m = fe_add<F>(m, t);
     }
+    fe_store<F>(Cc, c, fe_add<F>(a, fe_mul<F>(u, m)));
     fe_store<F>(A, c, a);
-    fe_store<F>(M, c, m);
-}
-template <class F> __global__ void uw_tables_kernel(const void *__restrict__ W, size_t n, Fe<F> u, void *__restrict__ upw, void *__restrict__ utw) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fe<F> x = fe_load<F>(W, i);
-    fe_store<F>(upw, i, fe_add<F>(u, x));
-    fe_store<F>(utw, i, fe_mul<F>(u, x));
 }
 // out[o] = sum over the gates with output o of op(in[left], in[right])   (arithmetic_circuit.rs:86-97, += semantics)
 template <class F> __global__ void circuit_layer_kernel(GateArrays g, const uint32_t *__restrict__ order, const uint32_t *__restrict__ start,
@@ -388,40 +378,37 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
             if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, eqB->dptr, load_el<F>(alpha), load_el<F>(beta), w.p);
         }
         ZK_HIP(hipGetLastError());
-        // phase 1: W H1 + H0 * 1
-        TablePtr H1, H0, ones;
+        // phase 1 (rounds over b): f = W(b) H1(b) + H0(b) * 1 -- the second product's factor is the constant one, never a table
+        TablePtr H1, H0;
         ZK_TRY(alloc_table(F::ID, nk, H1));
         ZK_TRY(alloc_table(F::ID, nk, H0));
-        ZK_TRY(alloc_table(F::ID, nk, ones));
         phase1_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_left.p, nk, w.p, (const uint32_t *)Ly.ord_left.p,
                                                          (const uint32_t *)Ly.l_right.p, (const uint32_t *)Ly.l_op.p, Wn->dptr, H1->dptr, H0->dptr);
-        fill_one_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(ones->dptr, nk);
         ZK_HIP(hipGetLastError());
         memcpy(layer_claims + l * L64, claim, L64 * 8);
         tr.t.append_be<F>(load_el<F>(claim));                                        // sumcheck_gkr_protocol.rs:35
         uint64_t *lco = coeffs + coff * L64, *lch = challenges + choff * L64;
-        uint64_t fin[4 * 6];
-        const zk_table *t1[4] = {Wn, H1.get(), H0.get(), ones.get()};
-        ZK_TRY(zk_sumcheck_gkr_rounds(t1, 2, 2, &tr, lco, lch, fin));                // rounds over b
+        uint64_t fin[4 * 6], cfs[2 * 6];
+        store_el<F>(cfs + L64, fe_one<F>());
+        const zk_table *t1[4] = {Wn, H1.get(), H0.get(), nullptr};
+        ZK_TRY(zk_sumcheck_gkr_rounds_cf(t1, 2, 2, cfs, &tr, lco, lch, fin));        // rounds over b
         uint64_t u[6];
         memcpy(u, fin, L64 * 8);                                                     // W(rb*)
-        // phase 2: A (u + W) + M (u W)
-        TablePtr eqL, A, M, upw, utw;
+        // phase 2 (rounds over c, b fixed to rb*): A(c) (u + W(c)) + M(c) u W(c) = C(c) W(c) + A(c) * u with C = A + u M
+        TablePtr eqL, Cc, A;
         ZK_TRY((eq_table<F>(lch, k, eqL)));
+        ZK_TRY(alloc_table(F::ID, nk, Cc));
         ZK_TRY(alloc_table(F::ID, nk, A));
-        ZK_TRY(alloc_table(F::ID, nk, M));
-        ZK_TRY(alloc_table(F::ID, nk, upw));
-        ZK_TRY(alloc_table(F::ID, nk, utw));
         phase2_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_right.p, nk, w.p, (const uint32_t *)Ly.ord_right.p,
-                                                         (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, eqL->dptr, A->dptr, M->dptr);
-        uw_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>(Wn->dptr, nk, load_el<F>(u), upw->dptr, utw->dptr);
+                                                         (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, eqL->dptr, load_el<F>(u), Cc->dptr, A->dptr);
         ZK_HIP(hipGetLastError());
-        const zk_table *t2[4] = {A.get(), upw.get(), M.get(), utw.get()};
-        ZK_TRY(zk_sumcheck_gkr_rounds(t2, 2, 2, &tr, lco + (size_t)k * 3 * L64, lch + (size_t)k * L64, fin));   // rounds over c
+        memcpy(cfs + L64, u, L64 * 8);
+        const zk_table *t2[4] = {Cc.get(), Wn, A.get(), nullptr};
+        ZK_TRY(zk_sumcheck_gkr_rounds_cf(t2, 2, 2, cfs, &tr, lco + (size_t)k * 3 * L64, lch + (size_t)k * L64, fin));   // rounds over c
         if (l + 1 < nlayers) {                                                       // gkr_protocol.rs:109-133
             uint64_t wce[6];
             Fe<F> wb = load_el<F>(u);
-            Fe<F> wc = fe_sub<F>(load_el<F>(fin + L64), wb);                         // (u + W)(rc*) - u = W(rc*)
+            Fe<F> wc = load_el<F>(fin + L64);                                        // W(rc*): the second table of phase 2
             store_el<F>(wce, wc);
             memcpy(wb_evals + l * L64, u, L64 * 8);
             memcpy(wc_evals + l * L64, wce, L64 * 8);

@@ -265,6 +265,21 @@ int check_sumpoly(const zk_table *const *tables, size_t nprod, size_t nfac) {
     return ZK_OK;
 }
 
+// the same checks with constant second factors allowed (null entries at odd positions, two-factor products)
+int check_sumpoly_cf(const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *const_factors) {
+    if (!tables || nprod == 0 || nfac != 2 || nprod > (size_t)kMaxProducts || !tables[0]) return ZK_E_ARG;
+    for (size_t k = 0; k < nprod * nfac; k++) {
+        if (!tables[k]) {
+            if ((k & 1) == 0 || !const_factors) return ZK_E_ARG;
+            continue;
+        }
+        if (tables[k]->field != tables[0]->field) return ZK_E_ARG;
+        if (!is_pow2(tables[k]->len)) return ZK_E_NOT_POW2;
+        if (tables[k]->len != tables[0]->len) return ZK_E_NVARS;
+    }
+    return ZK_OK;
+}
+
 template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t half, void *part, int grid) {
     if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
     else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
@@ -283,9 +298,7 @@ template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int np
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
-    static const int variant = [] { const char *e = getenv("ZK_FRE_VARIANT"); return e ? atoi(e) : 0; }();
     if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
-    else if (nfac == 2 && variant == 1) fold_round_evals_occ4_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
     else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
     else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
     ZK_HIP(hipGetLastError());
@@ -333,15 +346,21 @@ template <class F> const std::vector<Fe<F>> &sumcheck_basis(size_t npts) {
 }
 
 // ---- GKR sumcheck prover: sumcheck_gkr_protocol.rs:24-67 --------------------------------------------------
+// `const_factors` (nprod elements, may be null): where tables[p * 2 + 1] is null the second factor of product p is that constant
+// (sumcheck_kernels.cuh const_factor; two-factor products only)
 template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t nprod, size_t nfac, Transcript &tr,
-                                           uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values) {
+                                           uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values,
+                                           const uint64_t *const_factors = nullptr) {
     const size_t esz = 4 * F::N, L64 = F::N / 2;
     const size_t ntab = nprod * nfac, npts = nfac + 1;                 // degree() = polynomials.len() (:114, sum_polynomial.rs:88)
     size_t len = tables[0]->len;
     unsigned nvars = ilog2(len);                                       // :29
     if (nvars == 0) {
         if (final_values)
-            for (size_t k = 0; k < ntab; k++) ZK_HIP(zk::memcpy_on_stream(final_values + k * L64, tables[k]->dptr, esz, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < ntab; k++) {
+                if (tables[k]) ZK_HIP(zk::memcpy_on_stream(final_values + k * L64, tables[k]->dptr, esz, hipMemcpyDeviceToHost));
+                else memcpy(final_values + k * L64, const_factors + (k / nfac) * L64, esz);
+            }
         return ZK_OK;
     }
     DevBuf bufA, bufB;
@@ -357,7 +376,10 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
     DeviceRounds<F> dr;
     ZK_TRY(dr.init(tr, basis_flat, fin_slot + ntab));
     SumPolyTables tabs{};
-    for (size_t k = 0; k < ntab; k++) tabs.in[k] = tables[k]->dptr;
+    for (size_t k = 0; k < ntab; k++) {
+        tabs.in[k] = tables[k] ? tables[k]->dptr : nullptr;
+        if (!tables[k]) memcpy(tabs.cval[k / nfac], const_factors + (k / nfac) * L64, esz);
+    }
     {   // round 0 evaluations
         size_t half = len / 2;
         int grid = reduce_grid_for(half);
@@ -370,7 +392,7 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
     for (; cl > kTailLen; round++) {                                   // :37
         const void *rp = dr.slot_ptr(per * round + npts);              // :55, on the device
         size_t ol = cl / 2, q = cl / 4;
-        for (size_t k = 0; k < ntab; k++) tabs.out[k] = dst + k * ol * esz;
+        for (size_t k = 0; k < ntab; k++) tabs.out[k] = tables[k] ? dst + k * ol * esz : nullptr;
         int grid = reduce_grid_for(q);                                 // :57 fused with next round's :41
         // large rounds skip the products of the point 1: e(1) = p_round(r_round) - e(0), derived in the finish step
         // (dev_transcript.cuh kDerive1).  Below ~2^14 pair indices the helper wave's two products take longer than the
@@ -741,6 +763,15 @@ int zk_sumcheck_gkr_rounds(const zk_table *const *tables, size_t nprod, size_t n
     if ((nprod < 2 || nfac < 2) && tables[0]->len > 1) return ZK_E_NEED_TWO;
     ZK_TRY(require_device());
     ZK_DISPATCH_FIELD(tables[0]->field, return gkr_sumcheck_rounds<F>(tables, nprod, nfac, t->t, round_coeffs, challenges, final_values));
+    return ZK_OK;
+}
+int zk_sumcheck_gkr_rounds_cf(const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *const_factors, zk_transcript *t,
+                              uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values) {
+    ZK_TRY(check_sumpoly_cf(tables, nprod, nfac, const_factors));
+    if (!t || !round_coeffs || !challenges) return ZK_E_ARG;
+    if (nprod < 2 && tables[0]->len > 1) return ZK_E_NEED_TWO;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(tables[0]->field, return gkr_sumcheck_rounds<F>(tables, nprod, nfac, t->t, round_coeffs, challenges, final_values, const_factors));
     return ZK_OK;
 }
 int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_t *round_coeffs, size_t nrounds, size_t ncoef,

@@ -37,6 +37,8 @@ def _decl():
         "zk_prodpoly_reduce": [C.POINTER(vp), sz, vp],
         "zk_sumpoly_round_evals": [C.POINTER(vp), sz, sz, u64p],
         "zk_sumcheck_gkr_prove": [C.POINTER(vp), sz, sz, u64p, vp, u64p, u64p],
+        "zk_sumcheck_gkr_rounds": [C.POINTER(vp), sz, sz, vp, u64p, u64p, u64p],
+        "zk_sumcheck_gkr_rounds_cf": [C.POINTER(vp), sz, sz, u64p, vp, u64p, u64p, u64p],
         "zk_sumcheck_gkr_verify": [C.c_int, u64p, u64p, sz, sz, vp, u64p, u64p, C.POINTER(C.c_int)],
     }
     for name, args in sigs.items():
@@ -254,6 +256,23 @@ def prove(sum_polynomial, claimed_sum, transcript):
     cs = np.ascontiguousarray(claimed_sum, np.uint64).reshape(-1)
     L.check(_decl().zk_sumcheck_gkr_prove(arr, nprod, nfac, L.p64(cs), transcript._h, L.p64(co), L.p64(ch)))
     return SumcheckProverProof(cs.copy(), co[:n], ch[:n])
+
+
+def gkr_rounds_const_factors(field, tables, const_factors, transcript):
+    """the rounds of `prove` (:37-60, no claimed-sum append) on two-factor products whose second factor may be a constant:
+    tables[p] = (MultilinearPolynomial, MultilinearPolynomial or None), const_factors[p] used where the second one is None.
+    -> (coefficient rows, challenges, final values (2 per product))"""
+    nprod = len(tables)
+    flat = [t for prod in tables for t in prod]
+    arr = (C.c_void_p * len(flat))(*[t._h if t is not None else None for t in flat])
+    n = len(flat[0]).bit_length() - 1
+    Lm = limbs(field)
+    co = np.zeros((max(n, 1), 3, Lm), np.uint64)
+    ch = np.zeros((max(n, 1), Lm), np.uint64)
+    fin = np.zeros((2 * nprod, Lm), np.uint64)
+    cf = np.ascontiguousarray(const_factors, np.uint64).reshape(nprod, Lm)
+    L.check(_decl().zk_sumcheck_gkr_rounds_cf(arr, nprod, 2, L.p64(cf), transcript._h, L.p64(co), L.p64(ch), L.p64(fin)))
+    return co[:n], ch[:n], fin
 
 
 def verify(proof, transcript, field):
