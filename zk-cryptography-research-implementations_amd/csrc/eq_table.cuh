@@ -32,6 +32,8 @@ template <class F> struct EqSmallArgs {
     Fe<F> tau[2][kEqSmallBits];
     int nbits[2];
     void *out[2];
+    Fe<F> scale[2];          // table `which` times scale[which] when scaled[which] (folded into its high half table: 64 products)
+    int scaled[2];
 };
 template <class F> __global__ void __launch_bounds__(1024) eq_small_kernel(EqSmallArgs<F> a) {
     __shared__ Fe<F> th[1 << kEqDirectBits], tl[1 << kEqDirectBits];
@@ -50,6 +52,7 @@ template <class F> __global__ void __launch_bounds__(1024) eq_small_kernel(EqSma
                 const bool bit = (idx >> (nb - 1 - i)) & 1u;
                 acc = fe_mul<F>(acc, bit ? t : fe_sub<F>(fe_one<F>(), t));
             }
+            if (!low && a.scaled[which]) acc = fe_mul<F>(acc, a.scale[which]);
             (low ? tl : th)[idx] = acc;
         }
     }
@@ -77,13 +80,17 @@ template <class F> struct EqBuilder {
             else dst[i] = fe_zero<F>();
         }
     }
-    int build(const uint64_t *point, uint32_t nbits, void *out) {
+    // `scale` (may be null): the table times that constant, i.e. out[i] = scale * eq(point, i) -- the constant rides on the high
+    // half table, so a weighted sum alpha eq(rb, .) + beta eq(rc, .) costs its consumers no products (zkmle_gkr_sparse.hip)
+    int build(const uint64_t *point, uint32_t nbits, void *out, const Fe<F> *scale = nullptr) {
         if (nbits <= (uint32_t)kEqSmallBits) {
             EqSmallArgs<F> a;
             load_taus(a.tau[0], point, nbits);
             load_taus(a.tau[1], point, 0);
             a.nbits[0] = (int)nbits; a.nbits[1] = 0;
             a.out[0] = out; a.out[1] = nullptr;
+            a.scaled[0] = scale ? 1 : 0; a.scaled[1] = 0;
+            a.scale[0] = scale ? *scale : fe_zero<F>(); a.scale[1] = fe_zero<F>();
             eq_small_kernel<F><<<1, 1024, 0, cur_stream()>>>(a);
             ZK_HIP(hipGetLastError());
             return ZK_OK;
@@ -100,10 +107,12 @@ template <class F> struct EqBuilder {
             load_taus(a.tau[1], point + (size_t)hbits * (F::N / 2), lbits);
             a.nbits[0] = (int)hbits; a.nbits[1] = (int)lbits;
             a.out[0] = hi; a.out[1] = lo;
+            a.scaled[0] = scale ? 1 : 0; a.scaled[1] = 0;
+            a.scale[0] = scale ? *scale : fe_zero<F>(); a.scale[1] = fe_zero<F>();
             eq_small_kernel<F><<<2, 1024, 0, cur_stream()>>>(a);
             ZK_HIP(hipGetLastError());
         } else {
-            ZK_TRY(build(point, hbits, hi));
+            ZK_TRY(build(point, hbits, hi, scale));
             ZK_TRY(build(point + (size_t)hbits * (F::N / 2), lbits, lo));
         }
         const size_t n = (size_t)1 << nbits;

@@ -47,14 +47,15 @@ int alloc_table(int field, size_t len, TablePtr &out) {
 struct GateArrays {
     const uint32_t *out, *left, *right, *op;      // SoA on the device
 };
-// w[g] = alpha eqA[out_g] + beta eqB[out_g]   (eqB may be null: layer 0)
+// w[g] = eqA[out_g] + eqB[out_g] where the caller's tables already carry the weights: eqA = alpha eq(rb, .), eqB = beta eq(rc, .)
+// (eq_table.cuh: the constant is folded into a 64-entry half table), eqB null on layer 0 (w[g] = eq(ra, out_g)).  No products here:
+// one per gate costs ~40 us of whole-GPU VALU time at 2^22 gates (profiles/r2/gkr_round_kernel_variants.md).
 // (`out` is the output index of gate i in whatever order the caller wants the weights: gate order, or one of the grouped orders)
-template <class F> __global__ void gate_weights_kernel(const uint32_t *__restrict__ out, size_t n, const void *eqA, const void *eqB, Fe<F> alpha,
-                                                       Fe<F> beta, void *__restrict__ w) {
+template <class F> __global__ void gate_weights_kernel(const uint32_t *__restrict__ out, size_t n, const void *eqA, const void *eqB, void *__restrict__ w) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fe<F> v = fe_load<F>(eqA, out[i]);
-    if (eqB) v = fe_add<F>(fe_mul<F>(alpha, v), fe_mul<F>(beta, fe_load<F>(eqB, out[i])));
+    if (eqB) v = fe_add<F>(v, fe_load<F>(eqB, out[i]));
     fe_store<F>(w, i, v);
 }
 // one lane per left index b.  The gates' right indices and operations are stored once more grouped by left index (start[b] ..
@@ -297,10 +298,10 @@ int upload_layer(const zk_gate *g, size_t n, uint32_t out_bits, uint32_t in_bits
 inline unsigned blocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 // eq(point, .) over 2^nbits entries: outer products of the half tables (eq_table.cuh), a handful of launches
-template <class F> int eq_table(const uint64_t *point, uint32_t nbits, TablePtr &out) {
+template <class F> int eq_table(const uint64_t *point, uint32_t nbits, TablePtr &out, const Fe<F> *scale = nullptr) {
     ZK_TRY(alloc_table(F::ID, (size_t)1 << nbits, out));
     EqBuilder<F> eb;
-    return eb.build(point, nbits, out->dptr);
+    return eb.build(point, nbits, out->dptr, scale);
 }
 
 template <class F> int evaluate_layers(std::vector<LayerDev> &layers, const uint64_t *inputs, size_t ninputs, std::vector<TablePtr> &W) {
@@ -371,11 +372,12 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         ZK_TRY(w.alloc((ng ? ng : 1) * esz));
         if (l == 0) {
             ZK_TRY((eq_table<F>(ra.data(), Ly.out_bits, eqA)));
-            if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, nullptr, fe_zero<F>(), fe_zero<F>(), w.p);
+            if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, nullptr, w.p);
         } else {
-            ZK_TRY((eq_table<F>(rb.data(), Ly.out_bits, eqA)));
-            ZK_TRY((eq_table<F>(rc.data(), Ly.out_bits, eqB)));
-            if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, eqB->dptr, load_el<F>(alpha), load_el<F>(beta), w.p);
+            const Fe<F> al = load_el<F>(alpha), be = load_el<F>(beta);
+            ZK_TRY((eq_table<F>(rb.data(), Ly.out_bits, eqA, &al)));                  // alpha eq(rb, .)
+            ZK_TRY((eq_table<F>(rc.data(), Ly.out_bits, eqB, &be)));                  // beta eq(rc, .)
+            if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, eqB->dptr, w.p);
         }
         ZK_HIP(hipGetLastError());
         // phase 1 (rounds over b): f = W(b) H1(b) + H0(b) * 1 -- the second product's factor is the constant one, never a table
@@ -440,14 +442,14 @@ template <class F> int wiring_eval(const zk_gate *g, size_t ngates, uint32_t out
     LayerDev L;
     ZK_TRY(upload_layer(g, ngates, out_bits, in_bits, L));
     TablePtr eqA, eqB, eqL, eqR;
-    ZK_TRY((eq_table<F>(pa, out_bits, eqA)));
-    if (pb) ZK_TRY((eq_table<F>(pb, out_bits, eqB)));
+    const Fe<F> al = pb ? load_el<F>(alpha) : fe_zero<F>(), be = pb ? load_el<F>(beta) : fe_zero<F>();
+    ZK_TRY((eq_table<F>(pa, out_bits, eqA, pb ? &al : nullptr)));
+    if (pb) ZK_TRY((eq_table<F>(pb, out_bits, eqB, &be)));
     ZK_TRY((eq_table<F>(rb, in_bits, eqL)));
     ZK_TRY((eq_table<F>(rc, in_bits, eqR)));
     DevBuf w;
     ZK_TRY(w.alloc(ngates * esz));
-    gate_weights_kernel<F><<<blocks(ngates), kBlock, 0, cur_stream()>>>((const uint32_t *)L.out.p, ngates, eqA->dptr, pb ? eqB->dptr : nullptr,
-                                                        pb ? load_el<F>(alpha) : fe_zero<F>(), pb ? load_el<F>(beta) : fe_zero<F>(), w.p);
+    gate_weights_kernel<F><<<blocks(ngates), kBlock, 0, cur_stream()>>>((const uint32_t *)L.out.p, ngates, eqA->dptr, pb ? eqB->dptr : nullptr, w.p);
     int grid = reduce_grid_for(ngates);
     void *part;
     ZK_TRY(scratch(esz * ((size_t)grid * 2 + 2), &part));
