@@ -186,6 +186,64 @@ def op_gkr_sparse(zk, rng, field, mode):
     assert zk.gkr.sparse_verify(field, rows, ob, proof, x) is True
 
 
+def op_gkr_cf(zk, rng, field, mode, big=False):
+    """round 2: two-factor products whose second factor is a constant (zk_sumcheck_gkr_rounds_cf) against the oracle's proof of the
+    same SumPolynomial with the constant tables written out"""
+    nprod = int(rng.integers(2, 5))
+    logn = int(rng.integers(16, 19)) if big else int(rng.integers(1, 15))
+    if big:
+        nprod = 2
+    n = 1 << logn
+    MP = zk.MultilinearPolynomial
+    cvals = table(zk, rng, field, nprod, mode)
+    is_c = [bool(rng.integers(0, 2)) for _ in range(nprod)]
+    full = np.stack([np.stack([table(zk, rng, field, n, mode) for _ in range(2)]) for _ in range(nprod)])
+    for p in range(nprod):
+        if is_c[p]:
+            full[p, 1] = cvals[p]
+    tables = [(MP(field, full[p, 0]), None if is_c[p] else MP(field, full[p, 1])) for p in range(nprod)]
+    claimed = O.vec_sum(field, O.sumpoly_reduce(field, full))
+    prefix = bytes(rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8))
+    t_gpu, t_cpu = zk.Transcript(), O.Transcript()
+    t_gpu.append(prefix)
+    t_cpu.append(prefix)
+    t_gpu.append(O.fe_to_bytes_be(field, claimed))
+    co, ch, fin = zk.sumcheck.gkr_rounds_const_factors(field, tables, cvals, t_gpu)
+    wco, wch = O.sumcheck_gkr_prove(field, full, claimed, t_cpu)
+    assert np.array_equal(co, wco) and np.array_equal(ch, wch), ("gkr cf", field, nprod, logn, mode, is_c, len(prefix))
+    assert t_gpu.sample_random_challenge() == t_cpu.sample_random_challenge()
+    assert np.array_equal(fin[0], O.evaluate(field, full[0, 0], wch)), ("gkr cf final", field, nprod, logn, mode)
+
+
+def op_big_gkr_cf(zk, rng, field, mode):
+    op_gkr_cf(zk, rng, field, mode, True)
+
+
+def op_gkr_wide(zk, rng, field, mode):
+    """round 2: sparse GKR on circuits of arbitrary widths against the generalised dense big-int model (oracle/pymodel.py)"""
+    from oracle import pymodel as M
+    nl = int(rng.integers(1, 5))
+    widths = [int(rng.integers(1, 5)) for _ in range(nl + 1)]
+    p = O.modulus(field)
+    spec = []
+    for l in range(nl):
+        n_out, n_in = 1 << widths[l], 1 << widths[l + 1]
+        seen = set()
+        for _ in range(int(rng.integers(1, 2 * n_out + 2))):
+            seen.add((int(rng.integers(0, n_in)), int(rng.integers(0, n_in)), int(rng.integers(0, n_out)), int(rng.integers(0, 2))))
+        spec.append(sorted(seen, key=lambda g: (g[2], g[0], g[1], g[3])))
+    x = _ints(zk, rng, field, 1 << widths[nl], mode)
+    xs = zk.to_ints(field, x)
+    want = M.gkr_prove_wide(spec, widths[:nl], xs, p)
+    rows = [np.array(layer, np.uint64).reshape(-1, 4) for layer in spec]
+    proof = zk.gkr.sparse_prove(field, rows, widths[:nl], x)
+    assert zk.to_ints(field, proof.circuit_output) == want["circuit_output"], ("wide out", field, widths, spec)
+    assert [zk.to_ints(field, c) for c in proof.coeffs] == want["coeffs"], ("wide coeffs", field, widths, mode, spec)
+    assert zk.to_ints(field, proof.challenges) == want["challenges"], ("wide challenges", field, widths, mode, spec)
+    assert zk.to_ints(field, proof.wb_evals) == want["wb"] and zk.to_ints(field, proof.wc_evals) == want["wc"], ("wide wb/wc", field, widths, spec)
+    assert zk.to_ints(field, proof.claimed_sum.reshape(1, -1)) == [want["claimed_sum"]], ("wide claim", field, widths, spec)
+
+
 def op_elementwise(zk, rng, field, mode):
     MP = zk.MultilinearPolynomial
     logn = int(rng.integers(0, 8))
@@ -206,7 +264,7 @@ def op_big_basic(zk, rng, field, mode):
     op_basic(zk, rng, field, mode, True)
 
 
-OPS = {"big_gkr": op_big_gkr, "big_basic": op_big_basic, "gkr_dense": op_gkr_dense, "gkr_sparse": op_gkr_sparse, "elementwise": op_elementwise,
+OPS = {"big_gkr": op_big_gkr, "big_basic": op_big_basic, "big_gkr_cf": op_big_gkr_cf, "gkr_cf": op_gkr_cf, "gkr_wide": op_gkr_wide, "gkr_dense": op_gkr_dense, "gkr_sparse": op_gkr_sparse, "elementwise": op_elementwise,
        "fold": op_fold, "evaluate": op_evaluate, "basic_sumcheck": op_basic, "gkr_sumcheck": op_gkr_sumcheck, "msm": op_msm, "kzg": op_kzg}
 
 

@@ -65,6 +65,23 @@ class Transcript;
 // transcript.append(convert_to_bytes(table)) (evaluation_form.rs:35-43, prover.rs:38-39): the GPU converts Montgomery ->
 // canonical big-endian chunk by chunk into pinned host buffers while the host hashes the previous chunk (zkmle_sumcheck.hip)
 int transcript_absorb_table(Transcript &t, const zk_table *table);
+// Proof slots shared by a proof made of several sumchecks (zkmle_sumcheck.hip): the sponge, the interpolation basis and every slot
+// (coefficients, challenges, final values, layer links) live in ONE device block; rounds() and link() only enqueue kernels on the
+// current stream, collect() is the single download.  Slot layout of rounds(): round k's nfac + 1 coefficients at s0 + per k, its
+// challenge at s0 + per k + nfac + 1, then the nprod * nfac final values (per = nfac + 2).
+struct ProofSlotsBase {
+    virtual ~ProofSlotsBase() {}
+    virtual void *slot_ptr(size_t s) const = 0;                    // device address of slot s
+    virtual int upload_slot(size_t s, const uint64_t *el) = 0;
+    // enqueue the rounds of a sum-of-products sumcheck (constant second factors: tables[p * 2 + 1] == null, value from const_host
+    // (nprod elements) or const_dev[p] (device memory)); with_claim: proof[claim_slot] is absorbed in front of round 0's message
+    virtual int rounds(size_t s0, const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *const_host, const void *const *const_dev,
+                       int with_claim, size_t claim_slot) = 0;
+    // gkr_protocol.rs:109-133 on the device: append wb, alpha, append wc, beta, claim = alpha wb + beta wc
+    virtual int link(size_t wb_src, size_t wc_src, size_t wb_slot, size_t wc_slot, size_t alpha_slot, size_t beta_slot, size_t claim_slot) = 0;
+    virtual int collect(Transcript &tr, uint64_t *host_slots) = 0;   // every slot (field elements, u64 limbs) + the sponge back into tr
+};
+int proof_slots_new(int field, Transcript &tr, size_t npts, size_t nslots, ProofSlotsBase **out);
 // two pinned host staging buffers of at least `bytes` each, owned per device
 int pinned_pair(size_t bytes, void *out[2]);
 // a temporary table backed by the caching pool (internal provers: dozens of same-sized temporaries per proof)

@@ -213,8 +213,18 @@ __device__ __forceinline__ void round_message_and_challenge(RoundShared<F> &S, c
     } else {
         // coefficient d = sum_i ev[i] * basis[i][d]: the npts^2 products in the stored form and the npts^2 canonical ones
         // (for the bytes) are taken by 2 npts^2 lanes at once, then npts + npts lanes add them up
+        // with_claim (mode 1): the sumcheck's claimed sum, already in proof[claim_slot], is absorbed first, big-endian
+        // (sumcheck_gkr_protocol.rs:35) -- one message = the two appends; its canonical form rides along as one more product
         const int n2 = npts * npts;
+        const int off = with_claim ? F::N : 0;
         if ((int)lane < 2 * n2) S.pr[lane] = fe_mul<F>(S.ev[((int)lane % n2) / npts], fe_load<F>(c.basis, lane));
+        else if (with_claim && (int)lane == 2 * n2) {
+            Fe<F> one = fe_zero<F>();
+            one.l[0] = 1;
+            const Fe<F> cn = fe_mul<F>(fe_load<F>(c.proof, claim_slot), one);            // into_bigint()
+#pragma unroll
+            for (int k = 0; k < F::N; k++) S.msg[k] = __builtin_bswap32(cn.l[F::N - 1 - k]);
+        }
         wave_lds_sync();
         if ((int)lane < 2 * npts) {
             const int which = (int)lane / npts, d = (int)lane % npts;
@@ -224,7 +234,7 @@ __device__ __forceinline__ void round_message_and_challenge(RoundShared<F> &S, c
             if (which == 0) fe_store<F>(c.proof, msg_slot + d, m);
             else {
 #pragma unroll
-                for (int k = 0; k < F::N; k++) S.msg[d * F::N + k] = m.l[k];
+                for (int k = 0; k < F::N; k++) S.msg[off + d * F::N + k] = m.l[k];
             }
         }
     }
@@ -361,6 +371,46 @@ template <class F> __global__ void __launch_bounds__(128) limbs_finish_kernel(Li
     round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_slot, a.chal_slot, fill, lane, a.flags);
     if (lane < 25) a.ctx.sponge->a[lane] = S.st[lane];
     if (lane == 0) a.ctx.sponge->fill = fill;
+}
+
+// ---- between two layers of a GKR proof (gkr_protocol.rs:109-133), on the device ---------------------------------------------------
+// wb = W(rb*) and wc = W(rc*) are final values of the layer's sumcheck (proof slots); append wb, sample alpha, append wc, sample beta,
+// next claim = alpha wb + beta wc.  One wave; the sponge stays on the device, so a whole GKR proof is one stream of kernels.
+struct LinkArgs {
+    DevSponge *sponge;
+    void *proof;
+    size_t wb_src, wc_src;                   // slots holding W(rb*), W(rc*)
+    size_t wb_slot, wc_slot, alpha_slot, beta_slot, claim_slot;
+};
+template <class F> __global__ void __launch_bounds__(64) gkr_link_kernel(LinkArgs a) {
+    __shared__ RoundShared<F> S;
+    const unsigned lane = threadIdx.x;
+    if (lane < 25) S.st[lane] = a.sponge->a[lane];
+    uint32_t fill = a.sponge->fill;
+    wave_lds_sync();
+    const Fe<F> wb = fe_load<F>(a.proof, a.wb_src), wc = fe_load<F>(a.proof, a.wc_src);
+    Fe<F> ch[2];
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        if (lane == 0) {
+            const Fe<F> cn = fe_to_canonical<F>(k == 0 ? wb : wc);                       // field_element_to_bytes: big-endian (:125,:128)
+#pragma unroll
+            for (int i = 0; i < F::N; i++) S.msg[i] = __builtin_bswap32(cn.l[F::N - 1 - i]);
+        }
+        wave_lds_sync();
+        sponge_absorb_sample_wave(S.st, S.cl, S.tmp, fill, S.msg, 4u * F::N, lane);
+        ch[k] = challenge_from_digest<F>(S.msg + F::N);
+        wave_lds_sync();
+    }
+    if (lane == 0) {
+        fe_store<F>(a.proof, a.wb_slot, wb);
+        fe_store<F>(a.proof, a.wc_slot, wc);
+        fe_store<F>(a.proof, a.alpha_slot, ch[0]);
+        fe_store<F>(a.proof, a.beta_slot, ch[1]);
+        fe_store<F>(a.proof, a.claim_slot, fe_add<F>(fe_mul<F>(ch[0], wb), fe_mul<F>(ch[1], wc)));   // :132
+    }
+    if (lane < 25) a.sponge->a[lane] = S.st[lane];
+    if (lane == 0) a.sponge->fill = fill;
 }
 
 // ---- tail of a sumcheck: every round from a table of <= 4 kTailBlock entries down to one entry in ONE launch ----------

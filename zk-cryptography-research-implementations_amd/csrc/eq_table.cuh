@@ -34,6 +34,9 @@ template <class F> struct EqSmallArgs {
     void *out[2];
     Fe<F> scale[2];          // table `which` times scale[which] when scaled[which] (folded into its high half table: 64 products)
     int scaled[2];
+    const void *tau_dev[2];  // non-null: variable i of table `which` is element i * tau_stride of this device array (challenges an
+    size_t tau_stride;       // earlier kernel of the stream wrote into the proof slots), and the scale is *scale_dev[which]
+    const void *scale_dev[2];
 };
 template <class F> __global__ void __launch_bounds__(1024) eq_small_kernel(EqSmallArgs<F> a) {
     __shared__ Fe<F> th[1 << kEqDirectBits], tl[1 << kEqDirectBits];
@@ -48,11 +51,11 @@ template <class F> __global__ void __launch_bounds__(1024) eq_small_kernel(EqSma
             Fe<F> acc = fe_one<F>();
 #pragma unroll 1
             for (int i = 0; i < nb; i++) {
-                const Fe<F> t = a.tau[which][off + i];
+                const Fe<F> t = a.tau_dev[which] ? fe_load<F>(a.tau_dev[which], (size_t)(off + i) * a.tau_stride) : a.tau[which][off + i];
                 const bool bit = (idx >> (nb - 1 - i)) & 1u;
                 acc = fe_mul<F>(acc, bit ? t : fe_sub<F>(fe_one<F>(), t));
             }
-            if (!low && a.scaled[which]) acc = fe_mul<F>(acc, a.scale[which]);
+            if (!low && a.scaled[which]) acc = fe_mul<F>(acc, a.scale_dev[which] ? fe_load<F>(a.scale_dev[which], 0) : a.scale[which]);
             (low ? tl : th)[idx] = acc;
         }
     }
@@ -82,9 +85,46 @@ template <class F> struct EqBuilder {
     }
     // `scale` (may be null): the table times that constant, i.e. out[i] = scale * eq(point, i) -- the constant rides on the high
     // half table, so a weighted sum alpha eq(rb, .) + beta eq(rc, .) costs its consumers no products (zkmle_gkr_sparse.hip)
+    // the same from a point that lives in device memory (element i at dev + i * stride elements; scale_dev: one element or null)
+    int build_dev(const void *dev, size_t stride, uint32_t nbits, void *out, const void *scale_dev = nullptr) {
+        const size_t esz = 4 * F::N;
+        if (nbits <= (uint32_t)kEqSmallBits) {
+            EqSmallArgs<F> a{};
+            a.nbits[0] = (int)nbits; a.nbits[1] = 0;
+            a.out[0] = out; a.out[1] = nullptr;
+            a.tau_dev[0] = dev; a.tau_dev[1] = nullptr; a.tau_stride = stride;
+            a.scaled[0] = scale_dev ? 1 : 0; a.scale_dev[0] = scale_dev;
+            eq_small_kernel<F><<<1, 1024, 0, cur_stream()>>>(a);
+            ZK_HIP(hipGetLastError());
+            return ZK_OK;
+        }
+        const uint32_t hbits = nbits / 2, lbits = nbits - hbits;
+        void *hi = nullptr, *lo = nullptr;
+        ZK_TRY(pool_alloc(((size_t)1 << hbits) * esz, &hi));
+        temps.push_back(hi);
+        ZK_TRY(pool_alloc(((size_t)1 << lbits) * esz, &lo));
+        temps.push_back(lo);
+        const void *dev_lo = (const char *)dev + (size_t)hbits * stride * esz;
+        if (lbits <= (uint32_t)kEqSmallBits) {
+            EqSmallArgs<F> a{};
+            a.nbits[0] = (int)hbits; a.nbits[1] = (int)lbits;
+            a.out[0] = hi; a.out[1] = lo;
+            a.tau_dev[0] = dev; a.tau_dev[1] = dev_lo; a.tau_stride = stride;
+            a.scaled[0] = scale_dev ? 1 : 0; a.scale_dev[0] = scale_dev;
+            eq_small_kernel<F><<<2, 1024, 0, cur_stream()>>>(a);
+            ZK_HIP(hipGetLastError());
+        } else {
+            ZK_TRY(build_dev(dev, stride, hbits, hi, scale_dev));
+            ZK_TRY(build_dev(dev_lo, stride, lbits, lo));
+        }
+        const size_t n = (size_t)1 << nbits;
+        eq_outer_kernel<F><<<grid_for(n), kBlock, 0, cur_stream()>>>(hi, lo, lbits, n, out);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
     int build(const uint64_t *point, uint32_t nbits, void *out, const Fe<F> *scale = nullptr) {
         if (nbits <= (uint32_t)kEqSmallBits) {
-            EqSmallArgs<F> a;
+            EqSmallArgs<F> a{};
             load_taus(a.tau[0], point, nbits);
             load_taus(a.tau[1], point, 0);
             a.nbits[0] = (int)nbits; a.nbits[1] = 0;
@@ -102,7 +142,7 @@ template <class F> struct EqBuilder {
         ZK_TRY(pool_alloc(((size_t)1 << lbits) * 4 * F::N, &lo));
         temps.push_back(lo);
         if (lbits <= (uint32_t)kEqSmallBits) {                         // both halves in one launch
-            EqSmallArgs<F> a;
+            EqSmallArgs<F> a{};
             load_taus(a.tau[0], point, hbits);
             load_taus(a.tau[1], point + (size_t)hbits * (F::N / 2), lbits);
             a.nbits[0] = (int)hbits; a.nbits[1] = (int)lbits;

@@ -24,11 +24,14 @@ struct SumPolyTables {
     const void *in[kMaxProducts * kMaxFactors];   // [p * nfac + f]; nullptr = the CONSTANT factor cval[p] (second factor of a two-factor product)
     void *out[kMaxProducts * kMaxFactors];
     uint32_t cval[kMaxProducts][12];               // stored (Montgomery) form
+    const void *cptr[kMaxProducts];                // non-null: the constant is read from device memory instead (one element; a value an
+                                                   // earlier kernel of the same stream produced, e.g. u = W(rb*) of the sparse GKR prover)
 };
 // A product whose second factor is a constant c is a linear term: sum_i c X(i).  Its table is never materialised, loaded, folded or
 // stored (a constant folds to itself); the evaluation products use c directly.  The sparse GKR prover's phases are
 // W H1 + H0 * 1 and C W + A * u (zkmle_gkr_sparse.hip): three streamed tables instead of four.
 template <class F> __device__ __forceinline__ Fe<F> const_factor(const SumPolyTables &t, int p) {
+    if (t.cptr[p]) return fe_load<F>(t.cptr[p], 0);
     Fe<F> e;
 #pragma unroll
     for (int i = 0; i < F::N; i++) e.l[i] = t.cval[p][i];

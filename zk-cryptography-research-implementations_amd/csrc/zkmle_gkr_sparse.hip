@@ -83,9 +83,10 @@ template <class F> __global__ void phase1_tables_kernel(const uint32_t *__restri
 template <class F> __global__ void phase2_tables_kernel(const uint32_t *__restrict__ start, size_t nc, const void *__restrict__ w,
                                                         const uint32_t *__restrict__ order, const uint32_t *__restrict__ left_r,
                                                         const uint32_t *__restrict__ op_r,
-                                                        const void *__restrict__ eqL, Fe<F> u, void *__restrict__ Cc, void *__restrict__ A) {
+                                                        const void *__restrict__ eqL, const void *__restrict__ u_dev, void *__restrict__ Cc, void *__restrict__ A) {
     size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nc) return;
+    const Fe<F> u = fe_load<F>(u_dev, 0);                      // W(rb*): a final value of phase 1, still on the device
     Fe<F> a = fe_zero<F>(), m = fe_zero<F>();
     for (uint32_t e = start[c]; e < start[c + 1]; e++) {
         Fe<F> t = fe_mul<F>(fe_load<F>(w, order[e]), fe_load<F>(eqL, left_r[e]));
@@ -298,6 +299,12 @@ int upload_layer(const zk_gate *g, size_t n, uint32_t out_bits, uint32_t in_bits
 inline unsigned blocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 // eq(point, .) over 2^nbits entries: outer products of the half tables (eq_table.cuh), a handful of launches
+// the same from challenges that live in the proof slots on the device (element i at dev + i * stride elements)
+template <class F> int eq_table_dev(const void *dev, size_t stride, uint32_t nbits, TablePtr &out, const void *scale_dev = nullptr) {
+    ZK_TRY(alloc_table(F::ID, (size_t)1 << nbits, out));
+    EqBuilder<F> eb;
+    return eb.build_dev(dev, stride, nbits, out->dptr, scale_dev);
+}
 template <class F> int eq_table(const uint64_t *point, uint32_t nbits, TablePtr &out, const Fe<F> *scale = nullptr) {
     ZK_TRY(alloc_table(F::ID, (size_t)1 << nbits, out));
     EqBuilder<F> eb;
@@ -353,20 +360,33 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
     std::vector<uint64_t> ra((size_t)out_bits[0] * L64);
     for (uint32_t i = 0; i < out_bits[0]; i++) store_el<F>(ra.data() + i * L64, tr.t.random_challenge_as_field_element<F>());   // :50
     memcpy(output_challenges, ra.data(), ra.size() * 8);
-    uint64_t claim[6], alpha[6] = {0}, beta[6] = {0};
-    ZK_TRY(zk_mle_evaluate(W[0].get(), ra.data(), out_bits[0], claim));              // :51
-    std::vector<uint64_t> rb, rc;
-    size_t coff = 0, choff = 0;
+    uint64_t claim0[6];
+    ZK_TRY(zk_mle_evaluate(W[0].get(), ra.data(), out_bits[0], claim0));             // :51
+    tr.t.append_be<F>(load_el<F>(claim0));                                           // layer 0's sumcheck claim (sumcheck_gkr_protocol.rs:35)
+    // From here to the end the proof is ONE stream of kernels: the sponge, every round's coefficients and challenge, the final values of
+    // each phase (u = W(rb*), W(rc*)) and the alpha / beta / claim links between layers live in device proof slots; the table-building
+    // kernels read challenges and u from there.  One download at the end (round 1 synchronised 4 times per layer).
+    // Slots of layer l (k = in_bits): phase 1 at base: 4 k round slots + 4 final values; phase 2 the same; then wb, wc, alpha, beta, claim.
+    const size_t per = 4;
+    std::vector<size_t> base(nlayers + 1, 0);
+    for (size_t l = 0; l < nlayers; l++) base[l + 1] = base[l] + 2 * (per * layers[l].in_bits + 4) + 5;
+    ProofSlotsBase *psp = nullptr;
+    ZK_TRY(proof_slots_new(F::ID, tr.t, 3, base[nlayers], &psp));
+    std::unique_ptr<ProofSlotsBase> ps(psp);
+    std::vector<hipEvent_t> ev(ms_layers ? 2 * nlayers : 0);
+    for (hipEvent_t &e : ev) ZK_HIP(hipEventCreate(&e));
+    struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (hipEvent_t e : v) (void)hipEventDestroy(e); } } ev_guard{ev};
+    uint64_t one[2 * 6];
+    store_el<F>(one + L64, fe_one<F>());
     for (size_t l = 0; l < nlayers; l++) {                                           // :57
-        hipEvent_t e0, e1;
-        ZK_HIP(hipEventCreate(&e0));
-        ZK_HIP(hipEventCreate(&e1));
-        ZK_HIP(hipEventRecord(e0, cur_stream()));
+        if (ms_layers) ZK_HIP(hipEventRecord(ev[2 * l], cur_stream()));
         LayerDev &Ly = layers[l];
         const uint32_t k = Ly.in_bits;
         const size_t nk = (size_t)1 << k, ng = Ly.ngates;
         const zk_table *Wn = W[l + 1].get();
-        // gate weights
+        const size_t s1 = base[l], s2 = s1 + per * k + 4, lk = s2 + per * k + 4;      // phase 1, phase 2, link slots
+        // gate weights w_g = eq(ra, out_g) (layer 0) or alpha eq(rb, out_g) + beta eq(rc, out_g): the previous layer's challenges and
+        // alpha / beta are read from its slots, the constants folded into the eq half tables (eq_table.cuh)
         TablePtr eqA, eqB;
         DevBuf w;
         ZK_TRY(w.alloc((ng ? ng : 1) * esz));
@@ -374,9 +394,9 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
             ZK_TRY((eq_table<F>(ra.data(), Ly.out_bits, eqA)));
             if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, nullptr, w.p);
         } else {
-            const Fe<F> al = load_el<F>(alpha), be = load_el<F>(beta);
-            ZK_TRY((eq_table<F>(rb.data(), Ly.out_bits, eqA, &al)));                  // alpha eq(rb, .)
-            ZK_TRY((eq_table<F>(rc.data(), Ly.out_bits, eqB, &be)));                  // beta eq(rc, .)
+            const size_t p1 = base[l - 1], p2 = p1 + per * layers[l - 1].in_bits + 4, plk = p2 + per * layers[l - 1].in_bits + 4;
+            ZK_TRY((eq_table_dev<F>(ps->slot_ptr(p1 + 3), per, Ly.out_bits, eqA, ps->slot_ptr(plk + 2))));     // alpha eq(rb, .)
+            ZK_TRY((eq_table_dev<F>(ps->slot_ptr(p2 + 3), per, Ly.out_bits, eqB, ps->slot_ptr(plk + 3))));     // beta eq(rc, .)
             if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, eqB->dptr, w.p);
         }
         ZK_HIP(hipGetLastError());
@@ -387,52 +407,49 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         phase1_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_left.p, nk, w.p, (const uint32_t *)Ly.ord_left.p,
                                                          (const uint32_t *)Ly.l_right.p, (const uint32_t *)Ly.l_op.p, Wn->dptr, H1->dptr, H0->dptr);
         ZK_HIP(hipGetLastError());
-        memcpy(layer_claims + l * L64, claim, L64 * 8);
-        tr.t.append_be<F>(load_el<F>(claim));                                        // sumcheck_gkr_protocol.rs:35
-        uint64_t *lco = coeffs + coff * L64, *lch = challenges + choff * L64;
-        uint64_t fin[4 * 6], cfs[2 * 6];
-        store_el<F>(cfs + L64, fe_one<F>());
         const zk_table *t1[4] = {Wn, H1.get(), H0.get(), nullptr};
-        ZK_TRY(zk_sumcheck_gkr_rounds_cf(t1, 2, 2, cfs, &tr, lco, lch, fin));        // rounds over b
-        uint64_t u[6];
-        memcpy(u, fin, L64 * 8);                                                     // W(rb*)
-        // phase 2 (rounds over c, b fixed to rb*): A(c) (u + W(c)) + M(c) u W(c) = C(c) W(c) + A(c) * u with C = A + u M
+        // the layer's claim (alpha wb + beta wc of the previous link, already in its slot) is absorbed in front of round 0
+        ZK_TRY(ps->rounds(s1, t1, 2, 2, one, nullptr, l > 0 ? 1 : 0, l > 0 ? base[l - 1] + 2 * (per * layers[l - 1].in_bits + 4) + 4 : 0));
+        // phase 2 (rounds over c, b fixed to rb*, u = W(rb*) = phase 1's first final value):
+        // A(c) (u + W(c)) + M(c) u W(c) = C(c) W(c) + A(c) * u with C = A + u M
+        const void *u_dev = ps->slot_ptr(s1 + per * k);
         TablePtr eqL, Cc, A;
-        ZK_TRY((eq_table<F>(lch, k, eqL)));
+        ZK_TRY((eq_table_dev<F>(ps->slot_ptr(s1 + 3), per, k, eqL)));
         ZK_TRY(alloc_table(F::ID, nk, Cc));
         ZK_TRY(alloc_table(F::ID, nk, A));
         phase2_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_right.p, nk, w.p, (const uint32_t *)Ly.ord_right.p,
-                                                         (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, eqL->dptr, load_el<F>(u), Cc->dptr, A->dptr);
+                                                         (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, eqL->dptr, u_dev, Cc->dptr, A->dptr);
         ZK_HIP(hipGetLastError());
-        memcpy(cfs + L64, u, L64 * 8);
         const zk_table *t2[4] = {Cc.get(), Wn, A.get(), nullptr};
-        ZK_TRY(zk_sumcheck_gkr_rounds_cf(t2, 2, 2, cfs, &tr, lco + (size_t)k * 3 * L64, lch + (size_t)k * L64, fin));   // rounds over c
-        if (l + 1 < nlayers) {                                                       // gkr_protocol.rs:109-133
-            uint64_t wce[6];
-            Fe<F> wb = load_el<F>(u);
-            Fe<F> wc = load_el<F>(fin + L64);                                        // W(rc*): the second table of phase 2
-            store_el<F>(wce, wc);
-            memcpy(wb_evals + l * L64, u, L64 * 8);
-            memcpy(wc_evals + l * L64, wce, L64 * 8);
-            rb.assign(lch, lch + (size_t)k * L64);
-            rc.assign(lch + (size_t)k * L64, lch + (size_t)2 * k * L64);
-            tr.t.append_be<F>(wb);                                                   // :125
-            Fe<F> a = tr.t.random_challenge_as_field_element<F>();
-            tr.t.append_be<F>(wc);                                                   // :128
-            Fe<F> b = tr.t.random_challenge_as_field_element<F>();
-            store_el<F>(alpha, a);
-            store_el<F>(beta, b);
-            store_el<F>(claim, fe_add<F>(fe_mul<F>(a, wb), fe_mul<F>(b, wc)));       // :132
+        const void *cdev[2] = {nullptr, u_dev};
+        ZK_TRY(ps->rounds(s2, t2, 2, 2, nullptr, cdev, 0, 0));
+        if (l + 1 < nlayers)                                                         // gkr_protocol.rs:109-133, on the device
+            ZK_TRY(ps->link(s1 + per * k, s2 + per * k + 1, lk, lk + 1, lk + 2, lk + 3, lk + 4));
+        if (ms_layers) ZK_HIP(hipEventRecord(ev[2 * l + 1], cur_stream()));
+    }
+    std::vector<uint64_t> hs(base[nlayers] * L64);
+    ZK_TRY(ps->collect(tr.t, hs.data()));                                            // the proof's only download
+    auto slot = [&](size_t s) { return hs.data() + s * L64; };
+    size_t coff = 0, choff = 0;
+    for (size_t l = 0; l < nlayers; l++) {
+        const uint32_t k = layers[l].in_bits;
+        const size_t s1 = base[l], s2 = s1 + per * k + 4, lk = s2 + per * k + 4;
+        memcpy(layer_claims + l * L64, l == 0 ? claim0 : slot(base[l - 1] + 2 * (per * layers[l - 1].in_bits + 4) + 4), L64 * 8);
+        for (int ph = 0; ph < 2; ph++)
+            for (uint32_t j = 0; j < k; j++) {
+                const size_t s = (ph ? s2 : s1) + per * j;
+                memcpy(coeffs + (coff + ((size_t)ph * k + j) * 3) * L64, slot(s), 3 * L64 * 8);
+                memcpy(challenges + (choff + (size_t)ph * k + j) * L64, slot(s + 3), L64 * 8);
+            }
+        if (l + 1 < nlayers) {
+            memcpy(wb_evals + l * L64, slot(lk), L64 * 8);
+            memcpy(wc_evals + l * L64, slot(lk + 1), L64 * 8);
         }
         coff += (size_t)2 * k * 3;
         choff += (size_t)2 * k;
-        ZK_HIP(hipEventRecord(e1, cur_stream()));
-        ZK_HIP(hipEventSynchronize(e1));
-        if (ms_layers) (void)hipEventElapsedTime(&ms_layers[l], e0, e1);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        if (ms_layers) (void)hipEventElapsedTime(&ms_layers[l], ev[2 * l], ev[2 * l + 1]);
     }
-    memcpy(claimed_sum, claim, L64 * 8);
+    memcpy(claimed_sum, layer_claims + (nlayers - 1) * L64, L64 * 8);
     return ZK_OK;
 }
 

@@ -346,51 +346,42 @@ template <class F> const std::vector<Fe<F>> &sumcheck_basis(size_t npts) {
 }
 
 // ---- GKR sumcheck prover: sumcheck_gkr_protocol.rs:24-67 --------------------------------------------------
-// `const_factors` (nprod elements, may be null): where tables[p * 2 + 1] is null the second factor of product p is that constant
-// (sumcheck_kernels.cuh const_factor; two-factor products only)
-template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t nprod, size_t nfac, Transcript &tr,
-                                           uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values,
-                                           const uint64_t *const_factors = nullptr) {
+// Enqueue every round of a sum-of-products sumcheck on proof slots that already exist (no upload, no synchronisation): round k's
+// coefficients at s0 + per k, its challenge at s0 + per k + npts, the ntab final values at s0 + per nvars (per = npts + 1).
+// Constant second factors: tables[p * 2 + 1] == null, value from const_host (nprod elements) or const_dev[p] (device memory).
+// with_claim: proof[claim_slot] (already on the device) is absorbed big-endian in front of round 0's message (:35).
+template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const zk_table *const *tables, size_t nprod, size_t nfac,
+                                          const uint64_t *const_host, const void *const *const_dev, int with_claim, size_t claim_slot) {
     const size_t esz = 4 * F::N, L64 = F::N / 2;
     const size_t ntab = nprod * nfac, npts = nfac + 1;                 // degree() = polynomials.len() (:114, sum_polynomial.rs:88)
     size_t len = tables[0]->len;
     unsigned nvars = ilog2(len);                                       // :29
-    if (nvars == 0) {
-        if (final_values)
-            for (size_t k = 0; k < ntab; k++) {
-                if (tables[k]) ZK_HIP(zk::memcpy_on_stream(final_values + k * L64, tables[k]->dptr, esz, hipMemcpyDeviceToHost));
-                else memcpy(final_values + k * L64, const_factors + (k / nfac) * L64, esz);
-            }
-        return ZK_OK;
-    }
-    DevBuf bufA, bufB;
+    DevBuf bufA, bufB;                                                 // pooled: stream-ordered, safe to release once enqueued
     ZK_TRY(bufA.alloc(ntab * (len / 2) * esz));
-    ZK_TRY(bufB.alloc(ntab * (len / 4) * esz));
+    ZK_TRY(bufB.alloc(ntab * (len / 4 ? len / 4 : 1) * esz));
     void *part;
     ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
-    const std::vector<Fe<F>> &basis_flat = sumcheck_basis<F>(npts);    // :46-50, nodes 0..d never change
-    // Proof slots: round k: (npts+1)k .. +npts-1 = coefficients (:49-52), +npts = challenge (:55); then ntab final values.
     // Interpolation, absorb and challenge of every round run in the finish kernel (dev_transcript.cuh).
-    const size_t per = npts + 1, fin_slot = per * nvars;
-    const double t1 = now_ms();
-    DeviceRounds<F> dr;
-    ZK_TRY(dr.init(tr, basis_flat, fin_slot + ntab));
+    const size_t per = npts + 1, fin_slot = s0 + per * nvars;
     SumPolyTables tabs{};
     for (size_t k = 0; k < ntab; k++) {
         tabs.in[k] = tables[k] ? tables[k]->dptr : nullptr;
-        if (!tables[k]) memcpy(tabs.cval[k / nfac], const_factors + (k / nfac) * L64, esz);
+        if (!tables[k]) {
+            if (const_dev && const_dev[k / nfac]) tabs.cptr[k / nfac] = const_dev[k / nfac];
+            else memcpy(tabs.cval[k / nfac], const_host + (k / nfac) * L64, esz);
+        }
     }
     {   // round 0 evaluations
         size_t half = len / 2;
         int grid = reduce_grid_for(half);
         ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
-        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, 0, npts));
+        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, with_claim, claim_slot, s0, s0 + npts));
     }
     char *dst = (char *)bufA.p, *other = (char *)bufB.p;
     size_t cl = len;
     unsigned round = 0;
     for (; cl > kTailLen; round++) {                                   // :37
-        const void *rp = dr.slot_ptr(per * round + npts);              // :55, on the device
+        const void *rp = dr.slot_ptr(s0 + per * round + npts);         // :55, on the device
         size_t ol = cl / 2, q = cl / 4;
         for (size_t k = 0; k < ntab; k++) tabs.out[k] = tables[k] ? dst + k * ol * esz : nullptr;
         int grid = reduce_grid_for(q);                                 // :57 fused with next round's :41
@@ -399,7 +390,7 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
         // reduction they hide behind, so small rounds evaluate the point 1 directly (measured r1: 4 x 2^22 1.28 -> 1.23 ms).
         const int skip1 = q >= ((size_t)1 << 14) ? 1 : 0;
         ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true)));
-        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, per * (round + 1), per * (round + 1) + npts, skip1, per));
+        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, s0 + per * (round + 1), s0 + per * (round + 1) + npts, skip1, per));
         for (size_t k = 0; k < ntab; k++) tabs.in[k] = tabs.out[k];
         char *nx = other;
         other = dst;
@@ -407,7 +398,33 @@ template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t
         cl = ol;
     }
     // rounds on <= kTailLen entries, the last fold and the final values: one launch
-    ZK_TRY(dr.launch_tail(tabs, dst, other, (int)nprod, (int)nfac, cl, 1, round, 0, npts, per, fin_slot));
+    return dr.launch_tail(tabs, dst, other, (int)nprod, (int)nfac, cl, 1, round, s0, s0 + npts, per, fin_slot);
+}
+
+// `const_factors` (nprod elements, may be null): where tables[p * 2 + 1] is null the second factor of product p is that constant
+// (sumcheck_kernels.cuh const_factor; two-factor products only)
+template <class F> int gkr_sumcheck_rounds(const zk_table *const *tables, size_t nprod, size_t nfac, Transcript &tr,
+                                           uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values,
+                                           const uint64_t *const_factors = nullptr) {
+    const size_t esz = 4 * F::N, L64 = F::N / 2;
+    const size_t ntab = nprod * nfac, npts = nfac + 1;
+    size_t len = tables[0]->len;
+    unsigned nvars = ilog2(len);
+    if (nvars == 0) {
+        if (final_values)
+            for (size_t k = 0; k < ntab; k++) {
+                if (tables[k]) ZK_HIP(zk::memcpy_on_stream(final_values + k * L64, tables[k]->dptr, esz, hipMemcpyDeviceToHost));
+                else memcpy(final_values + k * L64, const_factors + (k / nfac) * L64, esz);
+            }
+        return ZK_OK;
+    }
+    const std::vector<Fe<F>> &basis_flat = sumcheck_basis<F>(npts);    // :46-50, nodes 0..d never change
+    // Proof slots: round k: (npts+1)k .. +npts-1 = coefficients (:49-52), +npts = challenge (:55); then ntab final values.
+    const size_t per = npts + 1, fin_slot = per * nvars;
+    const double t1 = now_ms();
+    DeviceRounds<F> dr;
+    ZK_TRY(dr.init(tr, basis_flat, fin_slot + ntab));
+    ZK_TRY((gkr_rounds_enqueue<F>(dr, 0, tables, nprod, nfac, const_factors, nullptr, 0, 0)));
     ZK_TRY(dr.collect(tr));
     g_stats = zk_sumcheck_stats{nvars, 0.f, (float)(now_ms() - t1)};
     for (unsigned round = 0; round < nvars; round++) {
@@ -575,6 +592,43 @@ template <class F> struct RoundsImpl : RoundsBase {
 };
 
 }  // namespace
+
+// ---- proof slots shared by a whole multi-sumcheck proof (the sparse GKR prover): one upload, one stream of kernels, one download -------
+namespace zk {
+template <class F> struct ProofSlotsImpl : ProofSlotsBase {
+    DeviceRounds<F> dr;
+    void *slot_ptr(size_t s) const override { return dr.slot_ptr(s); }
+    int upload_slot(size_t s, const uint64_t *el) override {
+        ZK_HIP(hipMemcpyAsync(dr.slot_ptr(s), el, 4 * F::N, hipMemcpyHostToDevice, cur_stream()));
+        ZK_HIP(hipStreamSynchronize(cur_stream()));                    // `el` is the caller's stack
+        return ZK_OK;
+    }
+    int rounds(size_t s0, const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *const_host, const void *const *const_dev,
+               int with_claim, size_t claim_slot) override {
+        return gkr_rounds_enqueue<F>(dr, s0, tables, nprod, nfac, const_host, const_dev, with_claim, claim_slot);
+    }
+    int link(size_t wb_src, size_t wc_src, size_t wb_slot, size_t wc_slot, size_t alpha_slot, size_t beta_slot, size_t claim_slot) override {
+        LinkArgs a{dr.sponge(), dr.proof(), wb_src, wc_src, wb_slot, wc_slot, alpha_slot, beta_slot, claim_slot};
+        gkr_link_kernel<F><<<1, 64, 0, cur_stream()>>>(a);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    int collect(Transcript &tr, uint64_t *host_slots) override {
+        ZK_TRY(dr.collect(tr));
+        for (size_t k = 0; k < dr.nslots; k++) store_el<F>(host_slots + k * (F::N / 2), dr.slot(k));
+        return ZK_OK;
+    }
+};
+int proof_slots_new(int field, Transcript &tr, size_t npts, size_t nslots, ProofSlotsBase **out) {
+    ZK_DISPATCH_FIELD(field, {
+        auto *p = new ProofSlotsImpl<F>();
+        int rc = p->dr.init(tr, sumcheck_basis<F>(npts), nslots);
+        if (rc != ZK_OK) { delete p; return rc; }
+        *out = p;
+    });
+    return ZK_OK;
+}
+}  // namespace zk
 
 namespace zk {
 int transcript_absorb_table(Transcript &t, const zk_table *table) {
