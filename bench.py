@@ -134,6 +134,10 @@ def main():
     comm = S.Comm(device=None if (args.rehearse or world == 1) else torch.device("cuda", local_rank))
     if world > 1:
         collectives["library"] = comm.native_backend()      # "rccl": the library's own ncclCommInitRank communicator
+        if comm.native_note:                                # it could not be created: the provers' exchange goes over gloo, loudly
+            collectives["note"] = comm.native_note
+            collectives["backend"] += " + gloo (FALLBACK for the provers' exchange, host staged)"
+            args.rehearse = True
         if args.require_rccl and collectives["library"] != "rccl":
             raise SystemExit("bench.py --require-rccl: the provers' communicator is not RCCL")
 

@@ -112,6 +112,8 @@ class Comm:
         self.bytes_received = 0
         self._native = None
         self._keep = None
+        self._rccl_failed = False
+        self.native_note = None
 
     def backend(self):
         return self.dist.get_backend(self.group) if self.dist.is_initialized() else "none"
@@ -170,17 +172,47 @@ class Comm:
         if backend == "none":
             ops = HostOps()
             L.check(lib.zk_comm_from_host_ops(C.byref(ops), 1, 0, C.byref(h)))
-        elif backend == "nccl":
+        elif backend == "nccl" and not self._rccl_failed:
+            dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
             uid = np.zeros(128, np.uint8)
-            if self.rank == 0:
-                L.check(lib.zk_comm_unique_id(L.p8(uid)))
+            try:                                                    # every rank reaches the broadcast and the vote below, whatever fails
+                if self.rank == 0:
+                    L.check(lib.zk_comm_unique_id(L.p8(uid)))
+            except Exception as e:                                  # noqa: BLE001
+                self.native_note = f"zk_comm_unique_id failed ({e!r})"[:300]
+                self._rccl_failed = True
             if self.world > 1:
-                t = torch.from_numpy(uid).to(self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device()))
+                t = torch.from_numpy(uid).to(dev)
                 self.dist.broadcast(t, src=0, group=self.group)
                 uid = t.cpu().numpy()
-            L.check(lib.zk_comm_init_rccl(L.p8(np.ascontiguousarray(uid)), self.world, self.rank, C.byref(h)))
+            if not uid.any():
+                self._rccl_failed = True
+            if not self._rccl_failed:
+                try:
+                    L.check(lib.zk_comm_init_rccl(L.p8(np.ascontiguousarray(uid)), self.world, self.rank, C.byref(h)))
+                except Exception as e:                              # noqa: BLE001
+                    # the library could not create its RCCL communicator: the ranks agree on it (vote below) and carry the exchange
+                    # over a gloo group created for the purpose (host staged); native_note says so
+                    self.native_note = f"zk_comm_init_rccl failed ({e!r}); exchange callbacks over a gloo group instead"[:300]
+                    self._rccl_failed = True
+            flag = torch.tensor([1 if self._rccl_failed else 0], device=self.device if self.device is not None else "cuda")
+            if self.world > 1:
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, group=self.group)
+            if int(flag.item()):
+                if h.value:
+                    lib.zk_comm_free(h)
+                self._rccl_failed = True
+                self.native_note = self.native_note or "another rank could not create its RCCL communicator; exchange callbacks over gloo"
+                self.group = self.dist.new_group(backend="gloo") if self.world > 1 else None
+                self.device = None
+                return self.native()
         else:
             dist, group, world, rank = self.dist, self.group, self.world, self.rank
+            if self._rccl_failed and world == 1:
+                ops = HostOps()
+                L.check(lib.zk_comm_from_host_ops(C.byref(ops), 1, 0, C.byref(h)))
+                self._native = h
+                return h
 
             def view(ptr, nbytes):
                 return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (nbytes,)))
