@@ -435,6 +435,13 @@ int zk_sharded_mle_evaluate(zk_comm *c, const zk_table *shard, const uint64_t *v
  * all-gather of G affine points (96 B each), G - 1 additions.  Same point on every rank. */
 int zk_sharded_msm_g1(zk_comm *c, const zk_table *scalars_slice, const zk_g1_bases *bases_slice, int window_bits,
                       uint64_t *out12, zk_msm_stats *stats /* this rank's local MSM, may be NULL */);
+/* open_and_prove (multilinear_kzg.rs:50-126) of the low-bit-sharded table (local length 2^m, G = 2^k ranks, nopen = m + k opening
+ * values).  bases_local = the rank's own powers P_{j G + g} (the same low-bit shard of g1_powers_of_tau), key_local = the opening key
+ * of bases_local (zk_kzg_opening_key_new; NULL: built for the call).  The first m proofs are sums over the ranks of local MSMs, the
+ * last k are computed replicated from the G leftover entries and the G per-rank base totals: ONE all-gather of (m + 1) points + one
+ * element per rank.  evaluation and the m + k proofs are the single-device ones, on every rank. */
+int zk_sharded_kzg_open(zk_comm *c, const zk_table *shard, const zk_g1_bases *bases_local, const zk_kzg_opening_key *key_local,
+                        const uint64_t *opening, size_t nopen, uint64_t *evaluation, uint64_t *proofs /* (m + k) x 12 */);
 
 #ifdef __cplusplus
 }

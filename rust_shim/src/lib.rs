@@ -79,6 +79,8 @@ pub mod ffi {
                                              t: *mut zk_transcript, coeffs: *mut u64, challenges: *mut u64, final_values: *mut u64) -> c_int;
         pub fn zk_sharded_msm_g1(c: *mut c_void, scalars: *const zk_table, bases: *const zk_g1_bases, window_bits: c_int, out12: *mut u64,
                                  stats: *mut c_void) -> c_int;
+        pub fn zk_sharded_kzg_open(c: *mut c_void, shard: *const zk_table, bases_local: *const zk_g1_bases, key_local: *const c_void,
+                                   opening: *const u64, nopen: usize, evaluation: *mut u64, proofs: *mut u64) -> c_int;
         // device-resident rounds for one-process-per-GPU provers
         pub fn zk_rounds_new(field: c_int, mode: c_int, nprod: usize, nfac: usize, nrounds: usize, t: *mut zk_transcript,
                              out: *mut *mut c_void) -> c_int;

@@ -181,3 +181,32 @@ def run_rccl_world1(rank, port, field, table, sum_tables, claimed, scalars, poin
         np.savez(os.path.join(out_dir, "rank0.npz"), **res)
     finally:
         dist.destroy_process_group()
+
+
+def run_kzg_open(rank, world, port, backend, table, points, opening, out_dir):
+    """sharded open_and_prove: every rank holds the low-bit shard of the table and of the setup's G1 powers"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as G
+        zk = G.import_package()
+        from zkmle_amd import _lib
+        _lib.check(zk.lib().zk_init(0))
+        S = zk.sharded
+        comm = S.Comm(device=torch.device("cuda", 0) if backend == "nccl" else None)
+        poly = zk.MultilinearPolynomial.vector(0, np.ascontiguousarray(table[rank::world]))
+        bases = zk.G1Bases(np.ascontiguousarray(points[rank::world]))
+        ev, proofs = S.kzg_open_device(comm, poly, bases, opening)
+        commit = S.msm_device(comm, poly, bases)                       # low-bit slices are as good a partition of the terms as any
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ev=ev, proofs=proofs, commit=commit,
+                 backend=np.frombuffer(comm.native_backend().encode(), np.uint8))
+        comm.close()
+    finally:
+        dist.destroy_process_group()

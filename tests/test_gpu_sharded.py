@@ -97,3 +97,30 @@ def test_rccl_world_size_1_native_provers(logn):
     assert np.array_equal(res["msm"], O.kzg_commit(scalars, pts))
     assert np.array_equal(res["evaluate"], O.evaluate(field, table, table[:logn]))
     assert int(res["ncoll"][0]) >= 3
+
+
+@pytest.mark.parametrize("world,logn,backend", [(1, 3, "gloo"), (2, 1, "gloo"), (2, 4, "gloo"), (4, 2, "gloo"), (4, 5, "gloo"), (2, 6, "gloo"), (1, 4, "nccl")])
+def test_sharded_kzg_open_and_commit(world, logn, backend):
+    """open_and_prove / commit_to_polynomial (multilinear_kzg.rs:25-126) with the table and the setup's G1 powers low-bit-sharded over
+    the ranks (zk_sharded_kzg_open, zk_sharded_msm_g1): evaluation, every proof point and the commitment equal the oracle's naive
+    single-device opening; the "nccl" case runs the exchange over the library's own RCCL communicator (one rank)."""
+    import os
+    import tempfile
+    import torch.multiprocessing as mp
+    from test_sharded_cpu import free_port
+    from _sharded_workers import run_kzg_open
+    n = 1 << logn
+    table = rand_table(O.FR381, n, 500 + logn)
+    taus = rand_table(O.FR381, logn, 600 + logn)
+    pts = O.kzg_setup_g1(taus)
+    opening = rand_table(O.FR381, logn, 700 + logn)
+    want_ev, want_proofs = O.kzg_open(table, pts, opening)
+    want_commit = O.kzg_commit(table, pts)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(run_kzg_open, args=(world, free_port(), backend, table, pts, opening, d), nprocs=world, join=True)
+        results = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
+    for res in results:
+        assert np.array_equal(res["ev"], want_ev)
+        assert np.array_equal(res["proofs"], want_proofs)
+        assert np.array_equal(res["commit"], want_commit)
+        assert res["backend"].tobytes() == (b"rccl" if backend == "nccl" else b"host-ops")

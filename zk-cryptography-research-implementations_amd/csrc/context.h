@@ -82,6 +82,10 @@ struct ProofSlotsBase {
     virtual int collect(Transcript &tr, uint64_t *host_slots) = 0;   // every slot (field elements, u64 limbs) + the sponge back into tr
 };
 int proof_slots_new(int field, Transcript &tr, size_t npts, size_t nslots, ProofSlotsBase **out);
+// open_and_prove's body with the subtracted value and the leftover entry exposed (zkmle_kzg.hip; the sharded opening builds on it)
+int kzg_open_core(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg_opening_key *key, const uint64_t *opening, size_t nopen,
+                  const uint64_t *v_given, uint64_t *evaluation, uint64_t *proofs, uint64_t *last);
+int kzg_key_total(const zk_kzg_opening_key *k, const zk_g1_bases *g1, uint64_t *out12);
 // two pinned host staging buffers of at least `bytes` each, owned per device
 int pinned_pair(size_t bytes, void *out[2]);
 // a temporary table backed by the caching pool (internal provers: dozens of same-sized temporaries per proof)

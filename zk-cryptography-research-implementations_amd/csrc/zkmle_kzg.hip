@@ -578,6 +578,12 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
     *out = key.release();
     return ZK_OK;
 }
+// sum of all the bases of the key's setup = its last pre-summed level (one point), affine
+extern "C++" int zk::kzg_key_total(const zk_kzg_opening_key *k, const zk_g1_bases *g1, uint64_t *out12) {
+    const zk_g1_bases *lv = (k && k->nvars >= 1) ? k->level[k->nvars] : g1;
+    if (!lv || lv->n != 1) return ZK_E_ARG;
+    return zk_g1_bases_download(lv, out12);
+}
 int zk_kzg_opening_key_free(zk_kzg_opening_key *k) {
     if (!k) return ZK_OK;
     if (k->small_u) (void)hipFree(k->small_u);
@@ -614,10 +620,19 @@ static unsigned open_threads() {
 int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg_opening_key *key, const uint64_t *opening,
                 size_t nopen, size_t n_g2, uint64_t *evaluation, uint64_t *proofs) {
     if (!poly || !g1_powers || !opening || !evaluation || !proofs) return ZK_E_ARG;
+    if (nopen != n_g2) return ZK_E_KZG_LEN;                          // :60-64
+    return zk::kzg_open_core(poly, g1_powers, key, opening, nopen, nullptr, evaluation, proofs, nullptr);
+}
+
+// The body of open_and_prove.  `v_given` (may be null): the value to subtract instead of poly(opening) -- a rank of a sharded
+// opening passes the GLOBAL evaluation (its shard's own evaluation is something else), the replicated tail passes zero (its table is
+// already f - v).  `last` (may be null): the single entry left of f - v after all the folds.
+extern "C++" int zk::kzg_open_core(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg_opening_key *key, const uint64_t *opening,
+                      size_t nopen, const uint64_t *v_given, uint64_t *evaluation, uint64_t *proofs, uint64_t *last) {
+    if (!poly || !g1_powers || (!opening && nopen) || !evaluation || (!proofs && nopen)) return ZK_E_ARG;
     if (poly->field != ZK_FR381) return ZK_E_ARG;
     if (!is_pow2(poly->len)) return ZK_E_NOT_POW2;
     if (ilog2(poly->len) != nopen) return ZK_E_KZG_LEN;              // :55-59
-    if (nopen != n_g2) return ZK_E_KZG_LEN;                          // :60-64
     if (poly->len != g1_powers->n) return ZK_E_KZG_LEN;              // the zip of :100-103 needs equal lengths (asserted at commit :29)
     ZK_TRY(require_device());
     zk_kzg_opening_key *own = nullptr;
@@ -628,7 +643,8 @@ int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg
     int rc = ZK_OK;
     if (key->nvars != nopen) rc = ZK_E_KZG_LEN;
     zk_table *sub = nullptr, *nxt = nullptr;
-    if (rc == ZK_OK) rc = zk_mle_evaluate(poly, opening, nopen, evaluation);                    // :70
+    if (rc == ZK_OK && v_given) memcpy(evaluation, v_given, 32);
+    if (rc == ZK_OK && !v_given) rc = zk_mle_evaluate(poly, opening, nopen, evaluation);        // :70
     if (rc == ZK_OK) rc = zk_table_alloc(ZK_FR381, poly->len, &sub);
     if (rc == ZK_OK) rc = zk_mle_sub_scalar(poly, evaluation, sub, nullptr);                    // :74-80
     if (rc == ZK_OK && poly->len >= 2) rc = zk_table_alloc(ZK_FR381, poly->len / 2, &nxt);
@@ -658,6 +674,7 @@ int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg
         zk_table *tt = sub; sub = nxt; nxt = tt;
     }
     if (rc == ZK_OK && hipStreamSynchronize(cur_stream()) != hipSuccess) rc = ZK_E_HIP;
+    if (rc == ZK_OK && last && zk_table_download(sub, last) != ZK_OK) rc = ZK_E_HIP;               // `sub` has one entry left
     // proof_i = sum_j [blown_up(q)[j]] B_j  (:96-107)  ==  sum_k [q[k]] B^(i+1)_k : task i < nbig; task nbig = the batched small levels
     const size_t ntasks = nbig + (batched ? 1 : 0);
     auto run_task = [&](size_t k) -> int {

@@ -517,4 +517,74 @@ int zk_sharded_msm_g1(zk_comm *c, const zk_table *scalars_slice, const zk_g1_bas
     return ZK_OK;
 }
 
+// open_and_prove (multilinear_kzg.rs:50-126) of a low-bit-sharded table.  Proof i < m (the local variables): quotient and pre-summed
+// bases of round i pair global indices that share their low bits, so pi_i = sum over the ranks of a LOCAL MSM (local quotient x the
+// opening key of the rank's own bases P_{jG+g}) -- one all-gather of m points per rank and G - 1 additions per proof.  The last k
+// proofs come from the G-entry table of leftovers (one per rank) against the per-rank totals of the bases, both all-gathered, and
+// are computed replicated.
+int zk_sharded_kzg_open(zk_comm *c, const zk_table *shard, const zk_g1_bases *bases_local, const zk_kzg_opening_key *key_local,
+                        const uint64_t *opening, size_t nopen, uint64_t *evaluation, uint64_t *proofs) {
+    if (!c || !shard || !bases_local || !opening || !evaluation || !proofs) return ZK_E_ARG;
+    if (shard->field != ZK_FR381) return ZK_E_ARG;
+    if (!is_pow2(shard->len) || !is_pow2((size_t)c->nranks)) return ZK_E_NOT_POW2;
+    const size_t G = (size_t)c->nranks, m = ilog2(shard->len), k = ilog2(G);
+    if (nopen != m + k) return ZK_E_KZG_LEN;                                       // :55-59 on the global table
+    if (zk_g1_bases_len(bases_local) != shard->len) return ZK_E_KZG_LEN;
+    ZK_TRY(require_device());
+    zk_kzg_opening_key *own = nullptr;
+    if (!key_local && m >= 1) {
+        ZK_TRY(zk_kzg_opening_key_new(bases_local, &own));
+        key_local = own;
+    }
+    struct KeyGuard { zk_kzg_opening_key *k; ~KeyGuard() { zk_kzg_opening_key_free(k); } } key_guard{own};
+    uint64_t v[4], left[4], dummy[4];
+    ZK_TRY(zk_sharded_mle_evaluate(c, shard, opening, nopen, v));                  // :70, the global evaluation
+    memcpy(evaluation, v, 32);
+    // local rounds: this rank's share of the first m proofs, and its entry of (f - v) folded over the local variables
+    std::vector<uint64_t> mine(12 * (m ? m : 1), 0);
+    ZK_TRY(kzg_open_core(shard, bases_local, key_local, opening, m, v, dummy, mine.data(), left));
+    if (G == 1) {
+        memcpy(proofs, mine.data(), 96 * m);
+        return ZK_OK;
+    }
+    // exchange: [m partial proofs | total of the local bases | leftover entry] per rank, one all-gather
+    uint64_t total[12];
+    ZK_TRY(kzg_key_total(key_local, bases_local, total));
+    const size_t words = 12 * m + 12 + 4;
+    std::vector<uint64_t> sendh(words), allh(words * G);
+    memcpy(sendh.data(), mine.data(), 96 * m);
+    memcpy(sendh.data() + 12 * m, total, 96);
+    memcpy(sendh.data() + 12 * m + 12, left, 32);
+    DevBuf snd, rcv;
+    ZK_TRY(snd.alloc(words * 8));
+    ZK_TRY(rcv.alloc(words * 8 * G));
+    ZK_HIP(memcpy_on_stream(snd.p, sendh.data(), words * 8, hipMemcpyHostToDevice));
+    ZK_TRY(c->all_gather(snd.p, rcv.p, words * 8));
+    ZK_HIP(memcpy_on_stream(allh.data(), rcv.p, words * 8 * G, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < m; i++) {                                               // pi_i = sum_g pi_i^(g), same order on every rank
+        uint64_t acc[12], nx[12];
+        memcpy(acc, allh.data() + 12 * i, 96);
+        for (size_t g = 1; g < G; g++) {
+            ZK_TRY(zk_g1_add(acc, allh.data() + g * words + 12 * i, nx));
+            memcpy(acc, nx, 96);
+        }
+        memcpy(proofs + 12 * i, acc, 96);
+    }
+    // the last k rounds on the G leftovers (entry g = rank g: the low index bits are the last variables) against the G totals
+    std::vector<uint64_t> tab(4 * G), pts(12 * G);
+    for (size_t g = 0; g < G; g++) {
+        memcpy(pts.data() + 12 * g, allh.data() + g * words + 12 * m, 96);
+        memcpy(tab.data() + 4 * g, allh.data() + g * words + 12 * m + 12, 32);
+    }
+    zk_table *t = nullptr;
+    zk_g1_bases *b = nullptr;
+    ZK_TRY(zk_table_upload(ZK_FR381, tab.data(), G, &t));
+    int rc = zk_g1_bases_upload(pts.data(), G, &b);
+    const uint64_t zero[4] = {0, 0, 0, 0};
+    if (rc == ZK_OK) rc = kzg_open_core(t, b, nullptr, opening + 4 * m, k, zero, dummy, proofs + 12 * m, nullptr);
+    zk_table_free(t);
+    zk_g1_bases_free(b);
+    return rc;
+}
+
 }  // extern "C"

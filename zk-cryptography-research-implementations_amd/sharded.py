@@ -88,6 +88,8 @@ def _declare_host():
     lib.zk_sharded_sumcheck_gkr_prove.argtypes = [L.vp, vpp, L.sz, L.sz, u64p, L.vp, u64p, u64p, u64p]
     lib.zk_sharded_mle_evaluate.argtypes = [L.vp, L.vp, u64p, L.sz, u64p]
     lib.zk_sharded_msm_g1.argtypes = [L.vp, L.vp, L.vp, C.c_int, u64p, L.vp]
+    lib.zk_sharded_kzg_open.argtypes = [L.vp, L.vp, L.vp, L.vp, u64p, L.sz, u64p, u64p]
+    lib.zk_sharded_kzg_open.restype = C.c_int
     for name in ("zk_comm_unique_id", "zk_comm_init_rccl", "zk_comm_from_host_ops", "zk_comm_free", "zk_comm_stats",
                  "zk_comm_all_reduce_sum_i64", "zk_comm_all_gather", "zk_comm_broadcast", "zk_sharded_sumcheck_basic_prove",
                  "zk_sharded_sumcheck_gkr_prove", "zk_sharded_mle_evaluate", "zk_sharded_msm_g1"):
@@ -550,3 +552,15 @@ def msm_device(comm, scalars, bases, window_bits=0, with_stats=False):
     st = MsmStats()
     L.check(lib.zk_sharded_msm_g1(comm.native(), scalars._h, bases._h, window_bits, L.p64(out), C.byref(st)))
     return (out, st.as_dict()) if with_stats else out
+
+
+def kzg_open_device(comm, poly, bases_local, opening, key_local=None):
+    """open_and_prove (multilinear_kzg.rs:50-126) of the sharded table: poly = this rank's low-bit shard, bases_local = the same shard of
+    the setup's G1 powers.  -> (evaluation, proofs (m + k, 12)), the single-device opening on every rank"""
+    lib = _declare_host()
+    op = np.ascontiguousarray(opening, np.uint64).reshape(-1, 4)
+    ev = np.zeros(4, np.uint64)
+    proofs = np.zeros((op.shape[0], 12), np.uint64)
+    L.check(lib.zk_sharded_kzg_open(comm.native(), poly._h, bases_local._h, key_local._h if key_local is not None else None,
+                                    L.p64(op), op.shape[0], L.p64(ev), L.p64(proofs)))
+    return ev, proofs
