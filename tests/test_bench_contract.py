@@ -1,0 +1,69 @@
+"""bench.py's contract with the driver: the rank count it reports is the rank count it ran (CPU part), and on a GPU the JSON line has
+the keys the driver and the judge read (one small run and one two-rank rehearsal through the self-launcher)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=e, timeout=timeout, cwd=ROOT)
+
+
+def test_world_size_must_match_gpus_flag():
+    # under torchrun bench.py is ONE rank: a line for the wrong rank count must not be printed
+    p = run(["--gpus", "1", "--steps", "1"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=2 but --gpus 1" in (p.stderr + p.stdout)
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_rank_count_must_be_a_power_of_two():
+    p = run(["--gpus", "3", "--steps", "1"], env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "power of two" in (p.stderr + p.stdout)
+
+
+def last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_one_gpu_line_has_the_contract_keys():
+    p = run(["--steps", "5", "--warmup", "2", "--log-n", "16", "--msm-reps", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = last_json(p.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "collectives", "post_check"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert d["post_check"]["bit_exact_vs_oracle"] is True
+    m = d["msm"]
+    assert m["roofline"]["bound"].startswith("valu") and 0 < m["roofline"]["frac"] < 1.2 and m["cpu_baseline"]["all_cores"]["cores"] >= 1
+    c5 = d["config5_strong"]
+    assert c5["sumcheck"]["verifier_equations_hold"] is True and c5["msm"]["same_point_on_every_rank"] is True
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_rehearsal():
+    # `--gpus 2` with no WORLD_SIZE: the launcher starts the two ranks itself (both on cuda:0 over gloo with --rehearse)
+    p = run(["--gpus", "2", "--rehearse", "--steps", "4", "--warmup", "1", "--log-n", "14", "--msm-reps", "1", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["collectives"]["library"] == "host-ops" and "rehearsal" in d["collectives"]["backend"]
+    assert d["config5_strong"]["sumcheck"]["verifier_equations_hold"] is True
+    assert d["config5_strong"]["msm"]["same_point_on_every_rank"] is True
+    assert "ms_per_proof" in d["sharded_sumcheck"]
