@@ -137,7 +137,6 @@ def main():
         if comm.native_note:                                # it could not be created: the provers' exchange goes over gloo, loudly
             collectives["note"] = comm.native_note
             collectives["backend"] += " + gloo (FALLBACK for the provers' exchange, host staged)"
-            args.rehearse = True
         if args.require_rccl and collectives["library"] != "rccl":
             raise SystemExit("bench.py --require-rccl: the provers' communicator is not RCCL")
 
@@ -198,7 +197,7 @@ def main():
         per_chunk.append(marks[i].elapsed_time(marks[i + 1]) / cnt)
     kern_ms_median = statistics.median(per_chunk)
     if world > 1:
-        tt = torch.tensor([dt], device="cpu" if args.rehearse else "cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -275,8 +274,8 @@ def _barrier_time(world, fn, reps, rehearse):
     if world > 1:
         dist.barrier()
     dt = (time.perf_counter() - t0) / reps
-    if world > 1:
-        tt = torch.tensor([dt], device="cpu" if rehearse else "cuda", dtype=torch.float64)
+    if world > 1:                                          # the default group's backend decides where its tensors live
+        tt = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     return dt, outs[-1]
