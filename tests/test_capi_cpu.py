@@ -103,3 +103,29 @@ def test_synthetic_generator_is_reduced_and_reproducible(zk, field):
     p = O.modulus(field)
     ints = [O.limbs_to_int(row) for row in a]
     assert all(0 <= v < p for v in ints) and len(set(ints)) == 64
+
+
+def test_comm_handle_and_sharded_entry_points_without_gpu(zk):
+    """the multi-GPU boundary loads on a CPU-only host: a one-rank communicator needs no transport; the provers refuse to compute
+    without a device (no CPU fallback) and reject bad communicators before anything else"""
+    import torch
+    S = zk.sharded
+    lib = S._declare_host()
+    ops = S.HostOps()
+    h = C.c_void_p()
+    assert lib.zk_comm_from_host_ops(C.byref(ops), 1, 0, C.byref(h)) == 0
+    lib.zk_comm_rank.argtypes = [C.c_void_p]
+    lib.zk_comm_size.argtypes = [C.c_void_p]
+    assert lib.zk_comm_rank(h) == 0 and lib.zk_comm_size(h) == 1 and lib.zk_comm_backend(h) == b"host-ops"
+    rx, n = C.c_uint64(7), C.c_uint64(7)
+    assert lib.zk_comm_stats(h, C.byref(rx), C.byref(n)) == 0 and rx.value == 0 and n.value == 0
+    assert lib.zk_comm_from_host_ops(C.byref(ops), 2, 0, C.byref(C.c_void_p())) == -7     # two ranks need the four callbacks
+    assert lib.zk_comm_from_host_ops(C.byref(ops), 1, 1, C.byref(C.c_void_p())) == -7     # rank out of range
+    out = np.zeros(4, np.uint64)
+    assert lib.zk_sharded_sumcheck_basic_prove(None, None, 0, out.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                               out.ctypes.data_as(C.POINTER(C.c_uint64)), None) == -7
+    assert lib.zk_comm_free(h) == 0
+    if not torch.cuda.is_available():
+        uid = np.zeros(128, np.uint8)
+        hh = C.c_void_p()
+        assert lib.zk_comm_init_rccl(uid.ctypes.data_as(C.POINTER(C.c_uint8)), 1, 0, C.byref(hh)) == -9   # ZK_E_NO_DEVICE, before RCCL is opened
