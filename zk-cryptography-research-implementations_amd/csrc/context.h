@@ -39,6 +39,9 @@ hipError_t memset_on_stream(void *dst, int value, size_t bytes);
 int scratch(size_t bytes, void **out);
 // pinned host staging for small results (a few field elements)
 int host_staging(size_t bytes, void **out);
+// one page of pinned, COHERENT (fine-grained) host memory per thread and device, mapped into the device: the mailbox of the
+// host-assisted transcript step (dev_transcript.cuh HostMailbox).  *host and *dev address the same memory.
+int host_mailbox(void **host, void **dev);
 
 // Caching device allocator for per-call scratch (the MSM allocates several GB per call; hipMalloc / hipFree of
 // such blocks costs milliseconds).  Freed blocks are kept per THREAD and device and reused by that thread's later calls of

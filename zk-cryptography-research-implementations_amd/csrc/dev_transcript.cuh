@@ -146,6 +146,53 @@ template <class F> __device__ __forceinline__ Fe<F> challenge_from_digest(const 
     return fe_from_canonical<F>(v);
 }
 
+// ---- host-assisted transcript step: a mailbox in pinned, coherent host memory -------------------------------------------------------
+// Keccak-f[1600] costs one CPU core ~0.2 us and one GPU wave ~4.7 us (24 dependent rounds of two LDS exchanges each), and a round
+// of a sumcheck needs two of them plus a handful of dependent field products: ~12 us of the ~19 us a round's transcript step takes on the
+// device.  A GPU wave <-> host thread round trip through fine-grained host memory measures 2.9 us (tools/microbench_mailbox.hip).  So the
+// kernel that has reduced a round's evaluations writes them to the mailbox, bumps `gpu_seq` and spins (bounded) until the host thread that
+// is driving the proof has run the transcript step on its sponge (zkmle_sumcheck.hip HostRounds::service) and answered with the challenge.
+// The proving call polls instead of sleeping in hipStreamSynchronize; nothing else changes: same messages, same bytes absorbed.
+struct HostMailbox {
+    uint64_t gpu_seq;                   // last request the GPU posted
+    uint64_t pad0[15];
+    uint32_t ev[(kMaxFactors + 1) * 12];                // the round's evaluations, stored (Montgomery) form
+    uint32_t fin[kMaxProducts * kMaxFactors * 12];      // a tail's last post: the fully folded tables
+    uint64_t pad1[8];
+    uint64_t cpu_seq;                   // last request the host answered
+    uint64_t pad2[15];
+    uint32_t chal[12];                  // the answer: the round's challenge
+    uint32_t aux[2][12];                // a layer link's answer: alpha, beta
+    uint64_t aborted;                   // set by a kernel whose spin budget ran out (the host died or stalled > ~2 s): the kernel still ends
+};
+constexpr long long kMailboxSpinBudget = 3000000;       // polls of ~0.7 us each
+
+// wave 0, uniform: post `nel` elements from `src` (LDS) as request `seq`
+template <class F> __device__ __forceinline__ void mailbox_post(HostMailbox *mb, uint32_t *dst, const Fe<F> *src, int nel, uint64_t seq, unsigned lane) {
+    for (int k = (int)lane; k < nel * F::N; k += 64) dst[(k / F::N) * 12 + k % F::N] = src[k / F::N].l[k % F::N];
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __atomic_store_n(&mb->gpu_seq, seq, __ATOMIC_RELEASE);
+}
+// wave 0, uniform: wait (bounded) until the host has answered request `seq`
+__device__ __forceinline__ void mailbox_wait(HostMailbox *mb, uint64_t seq, unsigned lane) {
+    if (lane == 0) {
+        long long spins = 0;
+        while (__atomic_load_n(&mb->cpu_seq, __ATOMIC_ACQUIRE) < seq) {
+            if (++spins > kMailboxSpinBudget) { mb->aborted = seq; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_system();
+}
+template <class F> __device__ __forceinline__ Fe<F> mailbox_element(const uint32_t *src) {
+    Fe<F> e;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) e.l[i] = __builtin_nontemporal_load(src + i);
+    return e;
+}
+
 constexpr int kMaxPts = kMaxFactors + 1;
 
 // what a round's transcript step needs besides the evaluations
@@ -157,6 +204,7 @@ struct RoundCtx {
     const void *basis;       // mode 1: basis[i * npts + d] = coefficient d of l_i (Montgomery form), followed by the same
                              // npts^2 coefficients as canonical integers (ev * canonical = canonical product)
     void *proof;             // Fe slots
+    HostMailbox *mb;         // non-null: the transcript step runs on the host (mailbox above); sponge and basis are then unused
 };
 // The evaluation at 1 comes for free: the round polynomial the prover sent last satisfies p_k(r_k) = e_{k+1}(0) + e_{k+1}(1)
 // identically (both sides are the sum over the folded table), whatever sum was claimed from outside.  A producer that skips
@@ -259,6 +307,7 @@ struct FinishArgs {
     int flags;               // kDerive1: the block carries one extra wave that evaluates the previous round's message
     size_t claim_slot, msg_slot, chal_slot;
     size_t prev_msg_slot, prev_chal_slot;   // kDerive1
+    uint64_t seq;            // host-assisted step: the request number of this round
 };
 
 // One workgroup (64..1024 lanes, a multiple of 64).  Stage 1: every wave reduces its share of the partials, all npts
@@ -289,7 +338,7 @@ __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArg
             for (int t = 0; t < kMaxPts; t++) sh[t * 16 + wave] = acc[t];
         }
     }
-    if (tid < 25) S.st[tid] = a.ctx.sponge->a[tid];
+    if (tid < 25 && !a.ctx.mb) S.st[tid] = a.ctx.sponge->a[tid];
     __syncthreads();
     if (wave != 0) return;
     {   // cross-wave sums: lane t * 16 + w holds wave w's sum of evaluation t
@@ -300,6 +349,12 @@ __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArg
         wave_lds_sync();
     }
     TS(1);
+    if (a.ctx.mb) {                                          // the host runs the transcript step; the challenge comes back through the mailbox
+        mailbox_post<F>(a.ctx.mb, a.ctx.mb->ev, S.ev, npts, a.seq, lane);
+        mailbox_wait(a.ctx.mb, a.seq, lane);
+        if (lane == 0) fe_store<F>(a.ctx.proof, a.chal_slot, mailbox_element<F>(a.ctx.mb->chal));
+        return;
+    }
     uint32_t fill = a.ctx.sponge->fill;
     round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_slot, a.chal_slot, fill, lane, a.flags);
     if (lane < 25) a.ctx.sponge->a[lane] = S.st[lane];
@@ -413,6 +468,22 @@ template <class F> __global__ void __launch_bounds__(64) gkr_link_kernel(LinkArg
     if (lane == 0) a.sponge->fill = fill;
 }
 
+// host-assisted layer link: the host already has wb and wc (the tails' final values) and answers with alpha and beta
+struct LinkWaitArgs {
+    HostMailbox *mb;
+    void *proof;
+    uint64_t seq;
+    size_t alpha_slot, beta_slot;
+};
+template <class F> __global__ void __launch_bounds__(64) gkr_link_wait_kernel(LinkWaitArgs a) {
+    const unsigned lane = threadIdx.x;
+    mailbox_wait(a.mb, a.seq, lane);
+    if (lane == 0) {
+        fe_store<F>(a.proof, a.alpha_slot, mailbox_element<F>(a.mb->aux[0]));
+        fe_store<F>(a.proof, a.beta_slot, mailbox_element<F>(a.mb->aux[1]));
+    }
+}
+
 // ---- tail of a sumcheck: every round from a table of <= 4 kTailBlock entries down to one entry in ONE launch ----------
 // Below ~2^11 entries a round is pure latency (one lane's chain of ~16 dependent products + the transcript step); as two
 // launches per round it costs ~36 us, most of it launch, partial-sum round trip and a second reduction.  One workgroup keeps
@@ -431,6 +502,7 @@ struct TailArgs {
     size_t round;            // index of the round whose challenge folds `in` (already in proof[chal_base + per * round])
     size_t msg_base, chal_base, per;   // slots of round k: messages at msg_base + per k, challenge at chal_base + per k
     size_t fin_slot;         // ntab final values (only written when fin_slot != ~0)
+    uint64_t seq0;           // host-assisted step: request number of the tail's first round; the final values go out as one more request
 };
 
 template <class F, int NFAC>
@@ -439,8 +511,10 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
     __shared__ RoundShared<F> S;
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const size_t esz = 4 * F::N;
-    if (tid < 25) S.st[tid] = a.ctx.sponge->a[tid];
-    uint32_t fill = a.ctx.sponge->fill;
+    HostMailbox *const mb = a.ctx.mb;
+    if (tid < 25 && !mb) S.st[tid] = a.ctx.sponge->a[tid];
+    uint32_t fill = mb ? 0u : a.ctx.sponge->fill;
+    uint64_t seq = a.seq0;
     Fe<F> r = fe_load<F>(a.ctx.proof, a.chal_base + a.per * a.round);
     // table k of the current round: the caller's tables first, then slice k of the previous round's output buffer
     const char *prev = nullptr;
@@ -540,7 +614,19 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
         if (block_reduce_wide<F, NFAC + 1>(acc, sh, tot)) S.ev[tid] = tot;
         __syncthreads();
         round++;
-        if (tid < 64) round_message_and_challenge<F>(S, a.ctx, 0, 0, a.msg_base + a.per * round, a.chal_base + a.per * round, fill, lane);
+        if (tid < 64) {
+            if (mb) {                                        // transcript step on the host (HostMailbox)
+                mailbox_post<F>(mb, mb->ev, S.ev, NFAC + 1, seq, lane);
+                mailbox_wait(mb, seq, lane);
+                if (lane == 0) {
+                    S.chal = mailbox_element<F>(mb->chal);
+                    fe_store<F>(a.ctx.proof, a.chal_base + a.per * round, S.chal);
+                }
+                seq++;
+            } else {
+                round_message_and_challenge<F>(S, a.ctx, 0, 0, a.msg_base + a.per * round, a.chal_base + a.per * round, fill, lane);
+            }
+        }
         __syncthreads();                                     // also orders this round's global stores before the next round's loads
         r = S.chal;
         prev = dst;
@@ -559,6 +645,16 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
         }
         fe_store<F>((char *)a.buf[j & 1] + (size_t)tid * esz, 0, v);
         if (a.fin_slot != ~(size_t)0) fe_store<F>(a.ctx.proof, a.fin_slot + tid, v);
+        if (mb) {
+#pragma unroll
+            for (int i = 0; i < F::N; i++) mb->fin[tid * 12 + i] = v.l[i];
+        }
+    }
+    if (mb) {                                                // the final values: one more post, no answer awaited
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __atomic_store_n(&mb->gpu_seq, seq, __ATOMIC_RELEASE);
+        return;
     }
     if (tid < 25) a.ctx.sponge->a[tid] = S.st[tid];
     if (tid == 0) a.ctx.sponge->fill = fill;

@@ -28,6 +28,7 @@ struct DeviceScratch {
     size_t host_bytes = 0;
     void *pair[2] = {nullptr, nullptr};      // pinned double buffer of the transcript absorb
     size_t pair_bytes = 0;
+    void *mbox = nullptr, *mbox_dev = nullptr;   // coherent mailbox page (host-assisted transcript step)
 };
 static std::mutex g_mu;                                  // guards the caching pool
 // Reduction partials and staging buffers are per THREAD and per device: two threads driving distinct handles never share
@@ -40,6 +41,7 @@ struct ScratchSet {
             if (s.host) (void)hipHostFree(s.host);
             for (void *p : s.pair)
                 if (p) (void)hipHostFree(p);
+            if (s.mbox) (void)hipHostFree(s.mbox);
         }
     }
 };
@@ -90,6 +92,19 @@ int host_staging(size_t bytes, void **out) {
         s->host_bytes = want;
     }
     *out = s->host;
+    return ZK_OK;
+}
+
+int host_mailbox(void **host, void **dev) {
+    DeviceScratch *s;
+    ZK_TRY(current_scratch(&s));
+    if (!s->mbox) {
+        ZK_HIP(hipHostMalloc(&s->mbox, 4096, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(s->mbox, 0, 4096);
+        ZK_HIP(hipHostGetDevicePointer(&s->mbox_dev, s->mbox, 0));
+    }
+    *host = s->mbox;
+    *dev = s->mbox_dev;
     return ZK_OK;
 }
 

@@ -87,24 +87,61 @@ template <class F> int download_elems(const void *d, size_t n, Fe<F> *out) {
     return ZK_OK;
 }
 
-// Device-resident rounds (dev_transcript.cuh): one pooled block holds the sponge, the interpolation basis and the proof
-// slots; it is uploaded once before the first round and downloaded once after the last.
+// Whether the transcript step of a round runs on the host thread that drives the proof (dev_transcript.cuh HostMailbox: default) or on
+// the device (ZK_HOST_TRANSCRIPT=0; always for the zk_rounds_* handle of the multi-GPU provers, whose step sits behind an all-reduce).
+static bool host_transcript_default() {
+    static const bool v = [] { const char *e = getenv("ZK_HOST_TRANSCRIPT"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+// Rounds of one proof (dev_transcript.cuh): one pooled block holds the sponge, the interpolation basis and the proof slots.
+// Device mode: uploaded once before the first round and downloaded once after the last, every transcript step on the device.
+// Host mode: the kernels post each round's evaluations to the mailbox and wait for the challenge; this object runs the transcript
+// step (service()) on the caller's host sponge, in request order, and keeps the proof slots on the host; the device slots keep
+// what kernels read (challenges, final values, link values).
 template <class F> struct DeviceRounds {
     static constexpr size_t kHead = 256;               // DevSponge, padded
     DevBuf buf;
     size_t nbasis = 0, nslots = 0;
     std::vector<uint8_t> host;
+    // host mode
+    bool host_mode = false;
+    Transcript *htr = nullptr;
+    HostMailbox *mb = nullptr, *mb_dev = nullptr;
+    std::vector<Fe<F>> hs;                             // the proof slots, host copy
+    std::vector<Fe<F>> hbasis;                         // basis[i * npts + d], stored form
+    struct Req { int kind, mode, npts, with_claim, derive1, ntab; size_t claim_slot, msg_slot, chal_slot, fin_slot, s[7]; };
+    enum { kRound = 0, kFinal = 1, kLink = 2 };
+    std::vector<Req> reqs;
+    size_t served = 0;
+    Fe<F> running_claim = fe_zero<F>();                // p_k(r_k) of the last served round = e_{k+1}(0) + e_{k+1}(1)
+
     char *base() const { return (char *)buf.p; }
     DevSponge *sponge() const { return (DevSponge *)buf.p; }
     void *basis() const { return base() + kHead; }
     void *proof() const { return base() + kHead + nbasis * 4 * F::N; }
     void *slot_ptr(size_t s) const { return (char *)proof() + s * 4 * F::N; }
     size_t bytes() const { return kHead + (nbasis + nslots) * 4 * F::N; }
-    int init(Transcript &tr, const std::vector<Fe<F>> &basis_flat, size_t slots) {
+    int init(Transcript &tr, const std::vector<Fe<F>> &basis_flat, size_t slots, bool allow_host = true) {
         static_assert(sizeof(DevSponge) <= kHead, "sponge header");
         nbasis = basis_flat.size();
         nslots = slots;
         ZK_TRY(buf.alloc(bytes()));
+        host_mode = allow_host && host_transcript_default();
+        if (host_mode) {
+            void *h = nullptr, *d = nullptr;
+            ZK_TRY(host_mailbox(&h, &d));
+            mb = (HostMailbox *)h;
+            mb_dev = (HostMailbox *)d;
+            ZK_HIP(hipStreamSynchronize(cur_stream()));      // nothing of an earlier proof may still be looking at the mailbox
+            memset((void *)mb, 0, sizeof(HostMailbox));
+            htr = &tr;
+            hs.assign(nslots, fe_zero<F>());
+            hbasis = basis_flat;
+            reqs.clear();
+            served = 0;
+            return ZK_OK;
+        }
         host.assign(kHead + nbasis * 4 * F::N, 0);
         DevSponge sp{};
         tr.sponge().export_state(sp.a, &sp.fill);
@@ -113,7 +150,84 @@ template <class F> struct DeviceRounds {
         ZK_HIP(zk::memcpy_on_stream(buf.p, host.data(), host.size(), hipMemcpyHostToDevice));
         return ZK_OK;
     }
-    RoundCtx ctx(int npts, int mode) const { return RoundCtx{npts, mode, sponge(), basis(), proof()}; }
+    RoundCtx ctx(int npts, int mode) const { return RoundCtx{npts, mode, sponge(), basis(), proof(), host_mode ? mb_dev : nullptr}; }
+
+    // ---- host mode: the transcript steps, in request order ----
+    static Fe<F> mb_get(const uint32_t *src) {
+        Fe<F> e;
+        for (int i = 0; i < F::N; i++) e.l[i] = __atomic_load_n(src + i, __ATOMIC_RELAXED);
+        return e;
+    }
+    static void mb_put(uint32_t *dst, const Fe<F> &e) {
+        for (int i = 0; i < F::N; i++) __atomic_store_n(dst + i, e.l[i], __ATOMIC_RELAXED);
+    }
+    void serve_round(const Req &q) {
+        Fe<F> ev[kMaxPts];
+        for (int t = 0; t < q.npts; t++) ev[t] = mb_get(mb->ev + 12 * t);
+        if (q.derive1) ev[1] = fe_sub<F>(running_claim, ev[0]);                // the producer skipped the point 1 (dev_transcript.cuh kDerive1)
+        Fe<F> r;
+        if (q.mode == 0) {                                                     // prover.rs:50-58: the two half sums, big-endian
+            if (q.with_claim) {
+                hs[q.claim_slot] = fe_add<F>(ev[0], ev[1]);                    // :28
+                htr->template append_be<F>(hs[q.claim_slot]);                  // :40-41
+            }
+            for (int t = 0; t < q.npts; t++) { hs[q.msg_slot + t] = ev[t]; htr->template append_be<F>(ev[t]); }
+            r = htr->template random_challenge_as_field_element<F>();
+            running_claim = fe_add<F>(ev[0], fe_mul<F>(r, fe_sub<F>(ev[1], ev[0])));
+        } else {                                                               // sumcheck_gkr_protocol.rs:46-55: Lagrange coefficients, little-endian
+            if (q.with_claim) htr->template append_be<F>(hs[q.claim_slot]);    // :35
+            Fe<F> c[kMaxPts];
+            for (int d = 0; d < q.npts; d++) {
+                c[d] = fe_mul<F>(ev[0], hbasis[d]);
+                for (int i = 1; i < q.npts; i++) c[d] = fe_add<F>(c[d], fe_mul<F>(ev[i], hbasis[(size_t)i * q.npts + d]));
+                hs[q.msg_slot + d] = c[d];
+            }
+            for (int d = 0; d < q.npts; d++) htr->template append_le<F>(c[d]);
+            r = htr->template random_challenge_as_field_element<F>();
+            Fe<F> acc = c[q.npts - 1];
+            for (int d = q.npts - 2; d >= 0; d--) acc = fe_add<F>(fe_mul<F>(acc, r), c[d]);
+            running_claim = acc;
+        }
+        hs[q.chal_slot] = r;
+        mb_put(mb->chal, r);
+    }
+    void serve_link(const Req &q) {                                            // gkr_protocol.rs:125-132
+        const Fe<F> wb = hs[q.s[0]], wc = hs[q.s[1]];
+        htr->template append_be<F>(wb);
+        const Fe<F> al = htr->template random_challenge_as_field_element<F>();
+        htr->template append_be<F>(wc);
+        const Fe<F> be = htr->template random_challenge_as_field_element<F>();
+        hs[q.s[2]] = wb; hs[q.s[3]] = wc; hs[q.s[4]] = al; hs[q.s[5]] = be;
+        hs[q.s[6]] = fe_add<F>(fe_mul<F>(al, wb), fe_mul<F>(be, wc));
+        running_claim = hs[q.s[6]];
+        mb_put(mb->aux[0], al);
+        mb_put(mb->aux[1], be);
+    }
+    // answer every request that is ready; block = until all are answered (bounded: a kernel that gave up sets `aborted`)
+    int service(bool block) {
+        if (!host_mode) return ZK_OK;
+        const double t0 = block ? now_ms() : 0.0;
+        unsigned long polls = 0;
+        while (served < reqs.size()) {
+            const Req &q = reqs[served];
+            const uint64_t seq = served + 1;
+            if (q.kind != kLink && __atomic_load_n(&mb->gpu_seq, __ATOMIC_ACQUIRE) < seq) {
+                if (!block) return ZK_OK;
+                if ((++polls & 0xfffff) == 0 && (mb->aborted || now_ms() - t0 > 20000.0)) {
+                    set_last_error("host-assisted transcript step: the device did not post a round (aborted or stalled)");
+                    return ZK_E_HIP;
+                }
+                continue;
+            }
+            if (q.kind == kRound) serve_round(q);
+            else if (q.kind == kLink) serve_link(q);
+            else for (int k = 0; k < q.ntab; k++) hs[q.fin_slot + k] = mb_get(mb->fin + 12 * k);
+            __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
+            served++;
+        }
+        return ZK_OK;
+    }
+
     // derive_prev = 1: the producer skipped the point 1; it is derived from the previous round's message, whose slots precede
     // this round's by `per` (dev_transcript.cuh kDerive1)
     int launch_finish(const void *partials, size_t count, int npts, int mode, int with_claim, size_t claim_slot, size_t msg_slot,
@@ -122,13 +236,19 @@ template <class F> struct DeviceRounds {
         a.partials = partials; a.count = count; a.ctx = ctx(npts, mode); a.with_claim = with_claim; a.flags = derive_prev ? kDerive1 : 0;
         a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
         a.prev_msg_slot = msg_slot - per; a.prev_chal_slot = chal_slot - per;
+        if (host_mode) {                                    // the derivation moves to the host with the rest of the step
+            reqs.push_back(Req{kRound, mode, npts, with_claim, derive_prev, 0, claim_slot, msg_slot, chal_slot, 0, {0, 0, 0, 0, 0, 0, 0}});
+            a.seq = reqs.size();
+            a.flags = 0;
+            derive_prev = 0;
+        }
         size_t threads = (count + 63) / 64 * 64;          // one partial per lane up to 1024 lanes
         const size_t cap = (size_t)kFinishBlock - (derive_prev ? 64 : 0);
         if (threads > cap) threads = cap;
         if (derive_prev) threads += 64;                   // the helper wave
         sumcheck_finish_kernel<F><<<1, (int)threads, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
-        return ZK_OK;
+        return service(false);
     }
     // every remaining round of a sumcheck whose tables have <= kTailLen entries, one launch (dev_transcript.cuh)
     int launch_tail(const SumPolyTables &tabs, void *buf0, void *buf1, int nprod, int nfac, size_t len, int mode, size_t round,
@@ -136,14 +256,38 @@ template <class F> struct DeviceRounds {
         TailArgs a{};
         a.tabs = tabs; a.buf[0] = buf0; a.buf[1] = buf1; a.nprod = nprod; a.ntab = nprod * nfac; a.len = len;
         a.ctx = ctx(nfac + 1, mode); a.round = round; a.msg_base = msg_base; a.chal_base = chal_base; a.per = per; a.fin_slot = fin_slot;
+        if (host_mode) {
+            a.seq0 = reqs.size() + 1;
+            size_t rd = round;
+            for (size_t cl = len; cl >= 4; cl /= 2) {        // one request per fused round of the tail, then its final values
+                rd++;
+                reqs.push_back(Req{kRound, mode, nfac + 1, 0, 0, 0, 0, msg_base + per * rd, chal_base + per * rd, 0, {0, 0, 0, 0, 0, 0, 0}});
+            }
+            reqs.push_back(Req{kFinal, mode, nfac + 1, 0, 0, nprod * nfac, 0, 0, 0, fin_slot == ~(size_t)0 ? 0 : fin_slot, {0, 0, 0, 0, 0, 0, 0}});
+            if (fin_slot == ~(size_t)0) reqs.back().ntab = 0;
+        }
         if (nfac == 1) sumcheck_tail_kernel<F, 1><<<1, kTailBlock, 0, cur_stream()>>>(a);
         else if (nfac == 2) sumcheck_tail_kernel<F, 2><<<1, kTailBlock, 0, cur_stream()>>>(a);
         else sumcheck_tail_kernel<F, 3><<<1, kTailBlock, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
-        return ZK_OK;
+        return service(false);
+    }
+    // the layer link of a GKR proof in host mode: the host answers with alpha and beta once the two tails' final values are in
+    int launch_link_host(size_t wb_src, size_t wc_src, size_t wb_slot, size_t wc_slot, size_t alpha_slot, size_t beta_slot, size_t claim_slot) {
+        reqs.push_back(Req{kLink, 1, 0, 0, 0, 0, 0, 0, 0, 0, {wb_src, wc_src, wb_slot, wc_slot, alpha_slot, beta_slot, claim_slot}});
+        LinkWaitArgs a{mb_dev, proof(), (uint64_t)reqs.size(), alpha_slot, beta_slot};
+        gkr_link_wait_kernel<F><<<1, 64, 0, cur_stream()>>>(a);
+        ZK_HIP(hipGetLastError());
+        return service(false);
     }
     // the single synchronisation of the sumcheck: proof slots + sponge back to the host
     int collect(Transcript &tr) {
+        if (host_mode) {
+            ZK_TRY(service(true));
+            ZK_HIP(hipStreamSynchronize(cur_stream()));
+            if (mb->aborted) { set_last_error("host-assisted transcript step: a kernel gave up waiting for the host"); return ZK_E_HIP; }
+            return ZK_OK;                                   // `tr` is the sponge the steps ran on
+        }
         host.resize(bytes());
         ZK_HIP(zk::memcpy_on_stream(host.data(), buf.p, bytes(), hipMemcpyDeviceToHost));
         DevSponge sp;
@@ -152,9 +296,13 @@ template <class F> struct DeviceRounds {
         return ZK_OK;
     }
     Fe<F> slot(size_t s) const {
+        if (host_mode) return hs[s];
         Fe<F> e;
         memcpy(e.l, host.data() + kHead + (nbasis + s) * 4 * F::N, 4 * F::N);
         return e;
+    }
+    ~DeviceRounds() {                                       // never leave a kernel waiting on a mailbox nobody serves
+        if (host_mode && served < reqs.size()) { (void)service(true); (void)hipStreamSynchronize(cur_stream()); }
     }
 };
 
@@ -491,7 +639,7 @@ template <class F> struct RoundsImpl : RoundsBase {
         if (mode == 0) { msg_base = 1; chal_base = 3; per = 3; fin_slot = 1 + 3 * nrounds; }
         else { msg_base = 0; chal_base = npts; per = npts + 1; fin_slot = per * nrounds; }
         static const std::vector<Fe<F>> none;
-        return dr.init(tr, mode == 1 ? sumcheck_basis<F>(npts) : none, fin_slot + ntab);
+        return dr.init(tr, mode == 1 ? sumcheck_basis<F>(npts) : none, fin_slot + ntab, false);   // behind an all-reduce: device transcript
     }
     size_t limbs_len() const override { return npts * (F::N + 1); }
     int check_tables(const zk_table *const *t, size_t minlen) const {
@@ -608,6 +756,7 @@ template <class F> struct ProofSlotsImpl : ProofSlotsBase {
         return gkr_rounds_enqueue<F>(dr, s0, tables, nprod, nfac, const_host, const_dev, with_claim, claim_slot);
     }
     int link(size_t wb_src, size_t wc_src, size_t wb_slot, size_t wc_slot, size_t alpha_slot, size_t beta_slot, size_t claim_slot) override {
+        if (dr.host_mode) return dr.launch_link_host(wb_src, wc_src, wb_slot, wc_slot, alpha_slot, beta_slot, claim_slot);
         LinkArgs a{dr.sponge(), dr.proof(), wb_src, wc_src, wb_slot, wc_slot, alpha_slot, beta_slot, claim_slot};
         gkr_link_kernel<F><<<1, 64, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
