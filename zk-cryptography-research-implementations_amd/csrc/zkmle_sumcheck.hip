@@ -5,9 +5,13 @@
 // with one synchronisation per sumcheck.
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "context.h"
@@ -87,6 +91,51 @@ template <class F> int download_elems(const void *d, size_t n, Fe<F> *out) {
     return ZK_OK;
 }
 
+// The host side of the mailbox is served by a helper thread that makes NO HIP call: one per proving thread, created at its first
+// proof, spinning only while a proof is in flight.  The proving thread itself keeps enqueueing kernels and may block inside the
+// HIP runtime (an allocation, another thread's hipFree waiting for the device to drain ...): a kernel waiting for its challenge
+// must never depend on a thread that can be stuck behind that very kernel.
+class ServiceWorker {
+  public:
+    ServiceWorker() : th_([this] { run(); }) {}
+    ~ServiceWorker() {
+        { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
+        cv_.notify_one();
+        th_.join();
+    }
+    void start(std::function<void()> job) {                    // the previous job has finished (callers wait for it)
+        { std::lock_guard<std::mutex> lk(mu_); job_ = std::move(job); pending_.store(true, std::memory_order_release); }
+        cv_.notify_one();
+    }
+  private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            {   // proofs come in bursts: keep polling for ~0.3 ms after a job before sleeping (a wake-up costs tens of microseconds,
+                // a small proof lasts 200)
+                const double t0 = now_ms();
+                while (!pending_.load(std::memory_order_acquire) && now_ms() - t0 < 0.3) {}
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) || quit_; });
+                if (quit_ && !pending_.load()) return;
+                job = std::move(job_);
+                pending_.store(false, std::memory_order_release);
+            }
+            job();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    std::atomic<bool> pending_{false};
+    bool quit_ = false;
+    std::thread th_;                                           // last member: started after the others exist
+};
+static ServiceWorker &service_worker() {
+    static thread_local ServiceWorker w;
+    return w;
+}
+
 // Whether the transcript step of a round runs on the host thread that drives the proof (dev_transcript.cuh HostMailbox: default) or on
 // the device (ZK_HOST_TRANSCRIPT=0; always for the zk_rounds_* handle of the multi-GPU provers, whose step sits behind an all-reduce).
 static bool host_transcript_default() {
@@ -112,8 +161,11 @@ template <class F> struct DeviceRounds {
     std::vector<Fe<F>> hbasis;                         // basis[i * npts + d], stored form
     struct Req { int kind, mode, npts, with_claim, derive1, ntab; size_t claim_slot, msg_slot, chal_slot, fin_slot, s[7]; };
     enum { kRound = 0, kFinal = 1, kLink = 2 };
-    std::vector<Req> reqs;
-    size_t served = 0;
+    std::vector<Req> reqs;                             // appended by the proving thread, consumed in order by the service thread
+    std::mutex req_mu;
+    size_t served = 0;                                 // service thread only
+    std::atomic<bool> closing{false}, finished{true};
+    std::atomic<int> service_rc{ZK_OK};
     Fe<F> running_claim = fe_zero<F>();                // p_k(r_k) of the last served round = e_{k+1}(0) + e_{k+1}(1)
 
     char *base() const { return (char *)buf.p; }
@@ -140,6 +192,10 @@ template <class F> struct DeviceRounds {
             hbasis = basis_flat;
             reqs.clear();
             served = 0;
+            closing = false;
+            finished = false;
+            service_rc = ZK_OK;
+            service_worker().start([this] { service_loop(); });
             return ZK_OK;
         }
         host.assign(kHead + nbasis * 4 * F::N, 0);
@@ -203,21 +259,30 @@ template <class F> struct DeviceRounds {
         mb_put(mb->aux[0], al);
         mb_put(mb->aux[1], be);
     }
-    // answer every request that is ready; block = until all are answered (bounded: a kernel that gave up sets `aborted`)
-    int service(bool block) {
-        if (!host_mode) return ZK_OK;
-        const double t0 = block ? now_ms() : 0.0;
-        unsigned long polls = 0;
-        while (served < reqs.size()) {
-            const Req &q = reqs[served];
-            const uint64_t seq = served + 1;
-            if (q.kind != kLink && __atomic_load_n(&mb->gpu_seq, __ATOMIC_ACQUIRE) < seq) {
-                if (!block) return ZK_OK;
-                if ((++polls & 0xfffff) == 0 && (mb->aborted || now_ms() - t0 > 20000.0)) {
-                    set_last_error("host-assisted transcript step: the device did not post a round (aborted or stalled)");
-                    return ZK_E_HIP;
-                }
+    // the service thread's job for this proof: answer the requests in order as the kernels post them, until the proving thread has
+    // closed the list and everything is answered.  Bounded: a kernel that gave up sets `aborted`; 20 s without a post ends the job.
+    void service_loop() {
+        for (;;) {
+            Req q;
+            bool have;
+            {
+                std::lock_guard<std::mutex> lk(req_mu);
+                have = served < reqs.size();
+                if (have) q = reqs[served];
+            }
+            if (!have) {
+                if (closing.load(std::memory_order_acquire)) break;
                 continue;
+            }
+            const uint64_t seq = served + 1;
+            if (q.kind != kLink) {
+                const double t0 = now_ms();
+                unsigned long polls = 0;
+                bool ok = true;
+                while (__atomic_load_n(&mb->gpu_seq, __ATOMIC_ACQUIRE) < seq) {
+                    if ((++polls & 0xffff) == 0 && (__atomic_load_n(&mb->aborted, __ATOMIC_RELAXED) || now_ms() - t0 > 20000.0)) { ok = false; break; }
+                }
+                if (!ok) { service_rc = ZK_E_HIP; break; }
             }
             if (q.kind == kRound) serve_round(q);
             else if (q.kind == kLink) serve_link(q);
@@ -225,7 +290,23 @@ template <class F> struct DeviceRounds {
             __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
             served++;
         }
-        return ZK_OK;
+        // on failure, release every kernel that may still be waiting (they get a stale challenge; the call reports the error)
+        if (service_rc.load() != ZK_OK) __atomic_store_n(&mb->cpu_seq, ~(uint64_t)0 >> 1, __ATOMIC_RELEASE);
+        finished.store(true, std::memory_order_release);
+    }
+    void push_req(const Req &q) {
+        std::lock_guard<std::mutex> lk(req_mu);
+        reqs.push_back(q);
+    }
+    size_t nreq() {
+        std::lock_guard<std::mutex> lk(req_mu);
+        return reqs.size();
+    }
+    int close_service() {                                   // no further requests: wait for the service thread to answer the rest
+        if (!host_mode || finished.load(std::memory_order_acquire)) return service_rc.load();
+        closing.store(true, std::memory_order_release);
+        while (!finished.load(std::memory_order_acquire)) {}
+        return service_rc.load();
     }
 
     // derive_prev = 1: the producer skipped the point 1; it is derived from the previous round's message, whose slots precede
@@ -237,8 +318,8 @@ template <class F> struct DeviceRounds {
         a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
         a.prev_msg_slot = msg_slot - per; a.prev_chal_slot = chal_slot - per;
         if (host_mode) {                                    // the derivation moves to the host with the rest of the step
-            reqs.push_back(Req{kRound, mode, npts, with_claim, derive_prev, 0, claim_slot, msg_slot, chal_slot, 0, {0, 0, 0, 0, 0, 0, 0}});
-            a.seq = reqs.size();
+            push_req(Req{kRound, mode, npts, with_claim, derive_prev, 0, claim_slot, msg_slot, chal_slot, 0, {0, 0, 0, 0, 0, 0, 0}});
+            a.seq = nreq();
             a.flags = 0;
             derive_prev = 0;
         }
@@ -248,7 +329,7 @@ template <class F> struct DeviceRounds {
         if (derive_prev) threads += 64;                   // the helper wave
         sumcheck_finish_kernel<F><<<1, (int)threads, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
-        return service(false);
+        return ZK_OK;
     }
     // every remaining round of a sumcheck whose tables have <= kTailLen entries, one launch (dev_transcript.cuh)
     int launch_tail(const SumPolyTables &tabs, void *buf0, void *buf1, int nprod, int nfac, size_t len, int mode, size_t round,
@@ -257,34 +338,35 @@ template <class F> struct DeviceRounds {
         a.tabs = tabs; a.buf[0] = buf0; a.buf[1] = buf1; a.nprod = nprod; a.ntab = nprod * nfac; a.len = len;
         a.ctx = ctx(nfac + 1, mode); a.round = round; a.msg_base = msg_base; a.chal_base = chal_base; a.per = per; a.fin_slot = fin_slot;
         if (host_mode) {
-            a.seq0 = reqs.size() + 1;
+            a.seq0 = nreq() + 1;
             size_t rd = round;
             for (size_t cl = len; cl >= 4; cl /= 2) {        // one request per fused round of the tail, then its final values
                 rd++;
-                reqs.push_back(Req{kRound, mode, nfac + 1, 0, 0, 0, 0, msg_base + per * rd, chal_base + per * rd, 0, {0, 0, 0, 0, 0, 0, 0}});
+                push_req(Req{kRound, mode, nfac + 1, 0, 0, 0, 0, msg_base + per * rd, chal_base + per * rd, 0, {0, 0, 0, 0, 0, 0, 0}});
             }
-            reqs.push_back(Req{kFinal, mode, nfac + 1, 0, 0, nprod * nfac, 0, 0, 0, fin_slot == ~(size_t)0 ? 0 : fin_slot, {0, 0, 0, 0, 0, 0, 0}});
-            if (fin_slot == ~(size_t)0) reqs.back().ntab = 0;
+            const bool want_fin = fin_slot != ~(size_t)0;
+            push_req(Req{kFinal, mode, nfac + 1, 0, 0, want_fin ? nprod * nfac : 0, 0, 0, 0, want_fin ? fin_slot : 0, {0, 0, 0, 0, 0, 0, 0}});
         }
         if (nfac == 1) sumcheck_tail_kernel<F, 1><<<1, kTailBlock, 0, cur_stream()>>>(a);
         else if (nfac == 2) sumcheck_tail_kernel<F, 2><<<1, kTailBlock, 0, cur_stream()>>>(a);
         else sumcheck_tail_kernel<F, 3><<<1, kTailBlock, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
-        return service(false);
+        return ZK_OK;
     }
     // the layer link of a GKR proof in host mode: the host answers with alpha and beta once the two tails' final values are in
     int launch_link_host(size_t wb_src, size_t wc_src, size_t wb_slot, size_t wc_slot, size_t alpha_slot, size_t beta_slot, size_t claim_slot) {
-        reqs.push_back(Req{kLink, 1, 0, 0, 0, 0, 0, 0, 0, 0, {wb_src, wc_src, wb_slot, wc_slot, alpha_slot, beta_slot, claim_slot}});
-        LinkWaitArgs a{mb_dev, proof(), (uint64_t)reqs.size(), alpha_slot, beta_slot};
+        push_req(Req{kLink, 1, 0, 0, 0, 0, 0, 0, 0, 0, {wb_src, wc_src, wb_slot, wc_slot, alpha_slot, beta_slot, claim_slot}});
+        LinkWaitArgs a{mb_dev, proof(), (uint64_t)nreq(), alpha_slot, beta_slot};
         gkr_link_wait_kernel<F><<<1, 64, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
-        return service(false);
+        return ZK_OK;
     }
     // the single synchronisation of the sumcheck: proof slots + sponge back to the host
     int collect(Transcript &tr) {
         if (host_mode) {
-            ZK_TRY(service(true));
+            const int rc = close_service();
             ZK_HIP(hipStreamSynchronize(cur_stream()));
+            if (rc != ZK_OK) { set_last_error("host-assisted transcript step: the device did not post a round (aborted or stalled)"); return rc; }
             if (mb->aborted) { set_last_error("host-assisted transcript step: a kernel gave up waiting for the host"); return ZK_E_HIP; }
             return ZK_OK;                                   // `tr` is the sponge the steps ran on
         }
@@ -301,8 +383,11 @@ template <class F> struct DeviceRounds {
         memcpy(e.l, host.data() + kHead + (nbasis + s) * 4 * F::N, 4 * F::N);
         return e;
     }
-    ~DeviceRounds() {                                       // never leave a kernel waiting on a mailbox nobody serves
-        if (host_mode && served < reqs.size()) { (void)service(true); (void)hipStreamSynchronize(cur_stream()); }
+    ~DeviceRounds() {                                       // never leave a kernel waiting on a mailbox nobody serves, nor the service
+        if (host_mode && !finished.load()) {                // thread inside an object that is going away
+            (void)close_service();
+            (void)hipStreamSynchronize(cur_stream());
+        }
     }
 };
 
