@@ -313,7 +313,7 @@ def config5_leg(zk, comm, args, rank, world, collectives):
         cur = S.fe_add(field, rp[k, 0], m)
     ok = ok and np.array_equal(S.mle_evaluate(comm, table, ch), cur)
     out["sumcheck"] = {"what": f"Prover::prove rounds of the 2^{args.log_n} table ({rp.shape[0]} rounds), 2^{args.log_n}/{world} entries per rank, "
-                               "device-resident transcript, one all-reduce(SUM) of 18 int64 words per large round, replicated one-launch tail",
+                               "one all-reduce(SUM) of 18 int64 words per large round on the prover's stream, replicated one-launch tail, transcript step on each rank's host through the mailbox",
                        "ms_per_proof": dt * 1e3, "field_mul_per_s": (n_global - 1) / dt, "rounds": int(rp.shape[0]),
                        "collectives_per_proof": (nc1 - nc0) // 5, "bytes_received_per_proof": (rx1 - rx0) // 5,
                        "verifier_equations_hold": bool(ok)}
@@ -354,8 +354,8 @@ def sharded_gkr_sumcheck_leg(zk, comm, rank, world, collectives, log_local=20):
     dt, (co, ch, fin) = _barrier_time(world, lambda: S.sumcheck_gkr_prove_device(comm, shard, claimed, zk.Transcript()), 3,
                                       collectives["backend"].startswith("gloo"))
     rounds = int(co.shape[0])
-    return {"what": f"GKR sumcheck on 4 tables of 2^{log_local} entries per rank ({rounds} rounds over {world} ranks), device-resident "
-                    "transcript, one all-reduce(SUM) of 27 int64 words per large round", "ms_per_proof": dt * 1e3, "rounds": rounds,
+    return {"what": f"GKR sumcheck on 4 tables of 2^{log_local} entries per rank ({rounds} rounds over {world} ranks), "
+                    "one all-reduce(SUM) of 27 int64 words per large round", "ms_per_proof": dt * 1e3, "rounds": rounds,
             "ms_per_round": dt * 1e3 / rounds, "field_mul_per_s": 5.0 * 2 * n * world / dt, "backend": collectives["backend"]}
 
 

@@ -402,13 +402,14 @@ struct LimbsFinishArgs {
     int flags;               // kDerive1: launched with 128 lanes, the second wave evaluates the previous round's message
     size_t claim_slot, msg_slot, chal_slot;
     size_t prev_msg_slot, prev_chal_slot;
+    uint64_t seq;            // host-assisted step: the request number of this round
 };
 template <class F> __global__ void __launch_bounds__(128) limbs_finish_kernel(LimbsFinishArgs a) {
     __shared__ RoundShared<F> S;
     const unsigned lane = threadIdx.x & 63u;
     if (threadIdx.x >= 64) {
-        if (lane == 0) S.claim = previous_claim<F>(a.ctx, a.prev_msg_slot, a.prev_chal_slot);
-    } else if (lane < 25) S.st[lane] = a.ctx.sponge->a[lane];
+        if (lane == 0 && !a.ctx.mb) S.claim = previous_claim<F>(a.ctx, a.prev_msg_slot, a.prev_chal_slot);
+    } else if (lane < 25 && !a.ctx.mb) S.st[lane] = a.ctx.sponge->a[lane];
     if (threadIdx.x < 64 && (int)lane < a.ctx.npts) {
         Wide<F> w;
         uint64_t c = 0;
@@ -422,6 +423,12 @@ template <class F> __global__ void __launch_bounds__(128) limbs_finish_kernel(Li
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
+    if (a.ctx.mb) {                                          // every rank's host runs the same transcript step on the summed evaluations
+        mailbox_post<F>(a.ctx.mb, a.ctx.mb->ev, S.ev, a.ctx.npts, a.seq, lane);
+        mailbox_wait(a.ctx.mb, a.seq, lane);
+        if (lane == 0) fe_store<F>(a.ctx.proof, a.chal_slot, mailbox_element<F>(a.ctx.mb->chal));
+        return;
+    }
     uint32_t fill = a.ctx.sponge->fill;
     round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_slot, a.chal_slot, fill, lane, a.flags);
     if (lane < 25) a.ctx.sponge->a[lane] = S.st[lane];

@@ -135,6 +135,7 @@ static ServiceWorker &service_worker() {
     static thread_local ServiceWorker w;
     return w;
 }
+static thread_local int g_host_rounds_active = 0;           // one proof at a time per proving thread owns the mailbox and the worker
 
 // Whether the transcript step of a round runs on the host thread that drives the proof (dev_transcript.cuh HostMailbox: default) or on
 // the device (ZK_HOST_TRANSCRIPT=0; always for the zk_rounds_* handle of the multi-GPU provers, whose step sits behind an all-reduce).
@@ -154,7 +155,7 @@ template <class F> struct DeviceRounds {
     size_t nbasis = 0, nslots = 0;
     std::vector<uint8_t> host;
     // host mode
-    bool host_mode = false;
+    bool host_mode = false, owns_service = false;
     Transcript *htr = nullptr;
     HostMailbox *mb = nullptr, *mb_dev = nullptr;
     std::vector<Fe<F>> hs;                             // the proof slots, host copy
@@ -179,8 +180,10 @@ template <class F> struct DeviceRounds {
         nbasis = basis_flat.size();
         nslots = slots;
         ZK_TRY(buf.alloc(bytes()));
-        host_mode = allow_host && host_transcript_default();
+        host_mode = allow_host && host_transcript_default() && g_host_rounds_active == 0;
         if (host_mode) {
+            g_host_rounds_active++;
+            owns_service = true;
             void *h = nullptr, *d = nullptr;
             ZK_TRY(host_mailbox(&h, &d));
             mb = (HostMailbox *)h;
@@ -303,9 +306,11 @@ template <class F> struct DeviceRounds {
         return reqs.size();
     }
     int close_service() {                                   // no further requests: wait for the service thread to answer the rest
-        if (!host_mode || finished.load(std::memory_order_acquire)) return service_rc.load();
-        closing.store(true, std::memory_order_release);
-        while (!finished.load(std::memory_order_acquire)) {}
+        if (host_mode && !finished.load(std::memory_order_acquire)) {
+            closing.store(true, std::memory_order_release);
+            while (!finished.load(std::memory_order_acquire)) {}
+        }
+        if (owns_service) { owns_service = false; g_host_rounds_active--; }
         return service_rc.load();
     }
 
@@ -388,6 +393,7 @@ template <class F> struct DeviceRounds {
             (void)close_service();
             (void)hipStreamSynchronize(cur_stream());
         }
+        if (owns_service) { owns_service = false; g_host_rounds_active--; }
     }
 };
 
@@ -724,7 +730,7 @@ template <class F> struct RoundsImpl : RoundsBase {
         if (mode == 0) { msg_base = 1; chal_base = 3; per = 3; fin_slot = 1 + 3 * nrounds; }
         else { msg_base = 0; chal_base = npts; per = npts + 1; fin_slot = per * nrounds; }
         static const std::vector<Fe<F>> none;
-        return dr.init(tr, mode == 1 ? sumcheck_basis<F>(npts) : none, fin_slot + ntab, false);   // behind an all-reduce: device transcript
+        return dr.init(tr, mode == 1 ? sumcheck_basis<F>(npts) : none, fin_slot + ntab);
     }
     size_t limbs_len() const override { return npts * (F::N + 1); }
     int check_tables(const zk_table *const *t, size_t minlen) const {
@@ -787,7 +793,13 @@ template <class F> struct RoundsImpl : RoundsBase {
         a.flags = skipped1 ? kDerive1 : 0;
         a.claim_slot = 0; a.msg_slot = msg_base + per * round; a.chal_slot = chal_base + per * round;
         a.prev_msg_slot = a.msg_slot - per; a.prev_chal_slot = a.chal_slot - per;      // used with kDerive1 only (round >= 1)
-        limbs_finish_kernel<F><<<1, skipped1 ? 128 : 64, 0, cur_stream()>>>(a);
+        if (dr.host_mode) {                                  // the step runs on this rank's host (every rank's host does the same)
+            dr.push_req(typename DeviceRounds<F>::Req{DeviceRounds<F>::kRound, mode, (int)npts, a.with_claim, skipped1 ? 1 : 0, 0, a.claim_slot,
+                                                       a.msg_slot, a.chal_slot, 0, {0, 0, 0, 0, 0, 0, 0}});
+            a.seq = dr.nreq();
+            a.flags = 0;
+        }
+        limbs_finish_kernel<F><<<1, (skipped1 && !dr.host_mode) ? 128 : 64, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
         round++;
         return ZK_OK;
@@ -810,6 +822,7 @@ template <class F> struct RoundsImpl : RoundsBase {
         const size_t L64 = F::N / 2;
         if (!t || round != nrounds) return ZK_E_ARG;
         ZK_TRY(dr.collect(t->t));
+        if (dr.host_mode && dr.htr != &t->t) t->t = *dr.htr;                 // the steps ran on the transcript given at creation
         if (claimed_sum && mode == 0) store_el<F>(claimed_sum, dr.slot(0));
         for (size_t r = 0; r < nrounds; r++) {
             if (messages)
