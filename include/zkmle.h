@@ -214,7 +214,9 @@ int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_
  * zk_rounds_evals + zk_rounds_absorb on the gathered tables (no all-reduce: replicated) and zk_rounds_tail.
  * mode 0 = basic sumcheck (prover.rs:35-71; nprod = nfac = 1, messages = the two half sums, the claimed sum is
  * absorbed before round 0), mode 1 = GKR sumcheck rounds (sumcheck_gkr_protocol.rs:37-60).  `t` is read at creation
- * (everything absorbed so far) and written back by zk_rounds_collect. */
+ * (everything absorbed so far) and written back by zk_rounds_collect; keep it alive and untouched in between (by default the
+ * transcript step of a round runs on the calling thread's host side, on `t` itself: the kernels post the summed evaluations to a
+ * pinned mailbox and wait for the challenge -- ZK_HOST_TRANSCRIPT=0 keeps the step on the device). */
 typedef struct zk_rounds zk_rounds;
 int zk_rounds_new(int field, int mode, size_t nprod, size_t nfac, size_t nrounds, zk_transcript *t, zk_rounds **out);
 int zk_rounds_free(zk_rounds *r);
