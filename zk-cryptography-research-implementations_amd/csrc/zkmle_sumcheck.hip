@@ -181,11 +181,11 @@ template <class F> struct DeviceRounds {
         nslots = slots;
         ZK_TRY(buf.alloc(bytes()));
         host_mode = allow_host && host_transcript_default() && g_host_rounds_active == 0;
+        void *h = nullptr, *d = nullptr;
+        if (host_mode && host_mailbox(&h, &d) != ZK_OK) host_mode = false;   // no coherent pinned page on this system: the device runs the step
         if (host_mode) {
             g_host_rounds_active++;
             owns_service = true;
-            void *h = nullptr, *d = nullptr;
-            ZK_TRY(host_mailbox(&h, &d));
             mb = (HostMailbox *)h;
             mb_dev = (HostMailbox *)d;
             ZK_HIP(hipStreamSynchronize(cur_stream()));      // nothing of an earlier proof may still be looking at the mailbox
