@@ -85,6 +85,9 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
 
+    if os.environ.get("ZK_BENCH_WATCHDOG"):                   # diagnostics: dump every thread's stack and exit if a rank is stuck
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["ZK_BENCH_WATCHDOG"]), exit=True)
     import numpy as np
     import torch
     import torch.distributed as dist

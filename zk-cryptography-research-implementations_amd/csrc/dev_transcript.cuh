@@ -165,7 +165,7 @@ struct HostMailbox {
     uint32_t aux[2][12];                // a layer link's answer: alpha, beta
     uint64_t aborted;                   // set by a kernel whose spin budget ran out (the host died or stalled > ~2 s): the kernel still ends
 };
-constexpr long long kMailboxSpinBudget = 3000000;       // polls of ~0.7 us each
+constexpr long long kMailboxSpinBudget = 2000000;       // polls of ~0.7-1.5 us each: 1.5-3 s
 
 // wave 0, uniform: post `nel` elements from `src` (LDS) as request `seq`
 template <class F> __device__ __forceinline__ void mailbox_post(HostMailbox *mb, uint32_t *dst, const Fe<F> *src, int nel, uint64_t seq, unsigned lane) {
@@ -179,7 +179,9 @@ __device__ __forceinline__ void mailbox_wait(HostMailbox *mb, uint64_t seq, unsi
     if (lane == 0) {
         long long spins = 0;
         while (__atomic_load_n(&mb->cpu_seq, __ATOMIC_ACQUIRE) < seq) {
-            if (++spins > kMailboxSpinBudget) { mb->aborted = seq; break; }
+            // give up after the budget, and at once if an earlier wait of this proof already did: a proof whose host side is gone must
+            // drain in seconds, not in (rounds x budget)
+            if (++spins > kMailboxSpinBudget || __atomic_load_n(&mb->aborted, __ATOMIC_RELAXED) != 0) { mb->aborted = seq; break; }
             __builtin_amdgcn_s_sleep(1);
         }
     }

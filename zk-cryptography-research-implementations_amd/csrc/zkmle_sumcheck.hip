@@ -268,13 +268,17 @@ template <class F> struct DeviceRounds {
         for (;;) {
             Req q;
             bool have;
+            // `closing` is read BEFORE the list: every request is pushed before the list is closed, so a list seen empty after
+            // `closing` was seen set really is finished (the other order can miss the last requests if this thread is descheduled
+            // between the two reads)
+            const bool was_closing = closing.load(std::memory_order_acquire);
             {
                 std::lock_guard<std::mutex> lk(req_mu);
                 have = served < reqs.size();
                 if (have) q = reqs[served];
             }
             if (!have) {
-                if (closing.load(std::memory_order_acquire)) break;
+                if (was_closing) break;
                 continue;
             }
             const uint64_t seq = served + 1;
