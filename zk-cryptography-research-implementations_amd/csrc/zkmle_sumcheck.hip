@@ -263,7 +263,7 @@ template <class F> struct DeviceRounds {
         mb_put(mb->aux[1], be);
     }
     // the service thread's job for this proof: answer the requests in order as the kernels post them, until the proving thread has
-    // closed the list and everything is answered.  Bounded: a kernel that gave up sets `aborted`; 20 s without a post ends the job.
+    // closed the list and everything is answered.  Bounded: a kernel that gave up sets `aborted`; 8 s without a post ends the job.
     void service_loop() {
         for (;;) {
             Req q;
@@ -287,7 +287,7 @@ template <class F> struct DeviceRounds {
                 unsigned long polls = 0;
                 bool ok = true;
                 while (__atomic_load_n(&mb->gpu_seq, __ATOMIC_ACQUIRE) < seq) {
-                    if ((++polls & 0xffff) == 0 && (__atomic_load_n(&mb->aborted, __ATOMIC_RELAXED) || now_ms() - t0 > 20000.0)) { ok = false; break; }
+                    if ((++polls & 0xffff) == 0 && (__atomic_load_n(&mb->aborted, __ATOMIC_RELAXED) || now_ms() - t0 > 8000.0)) { ok = false; break; }
                 }
                 if (!ok) { service_rc = ZK_E_HIP; break; }
             }
@@ -312,7 +312,15 @@ template <class F> struct DeviceRounds {
     int close_service() {                                   // no further requests: wait for the service thread to answer the rest
         if (host_mode && !finished.load(std::memory_order_acquire)) {
             closing.store(true, std::memory_order_release);
-            while (!finished.load(std::memory_order_acquire)) {}
+            const double t0 = now_ms();
+            while (!finished.load(std::memory_order_acquire)) {
+                std::this_thread::yield();                   // the service thread may need this core
+                if (now_ms() - t0 > 60000.0) {               // its own limits are far below this: only a lost service thread (fork) gets here
+                    set_last_error("host-assisted transcript step: the service thread did not finish");
+                    service_rc = ZK_E_HIP;
+                    break;
+                }
+            }
         }
         if (owns_service) { owns_service = false; g_host_rounds_active--; }
         return service_rc.load();
