@@ -310,6 +310,7 @@ struct FinishArgs {
     size_t claim_slot, msg_slot, chal_slot;
     size_t prev_msg_slot, prev_chal_slot;   // kDerive1
     uint64_t seq;            // host-assisted step: the request number of this round
+    size_t chal_slot2;       // host-assisted pair of rounds (mle_kernels.cuh fold2_quarter_sums_kernel): the second challenge, ~0 = none
 };
 
 // One workgroup (64..1024 lanes, a multiple of 64).  Stage 1: every wave reduces its share of the partials, all npts
@@ -354,7 +355,10 @@ __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArg
     if (a.ctx.mb) {                                          // the host runs the transcript step; the challenge comes back through the mailbox
         mailbox_post<F>(a.ctx.mb, a.ctx.mb->ev, S.ev, npts, a.seq, lane);
         mailbox_wait(a.ctx.mb, a.seq, lane);
-        if (lane == 0) fe_store<F>(a.ctx.proof, a.chal_slot, mailbox_element<F>(a.ctx.mb->chal));
+        if (lane == 0) {
+            fe_store<F>(a.ctx.proof, a.chal_slot, mailbox_element<F>(a.ctx.mb->chal));
+            if (a.chal_slot2 != ~(size_t)0) fe_store<F>(a.ctx.proof, a.chal_slot2, mailbox_element<F>(a.ctx.mb->aux[0]));
+        }
         return;
     }
     uint32_t fill = a.ctx.sponge->fill;

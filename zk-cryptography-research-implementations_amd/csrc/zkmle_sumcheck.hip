@@ -161,7 +161,7 @@ template <class F> struct DeviceRounds {
     std::vector<Fe<F>> hs;                             // the proof slots, host copy
     std::vector<Fe<F>> hbasis;                         // basis[i * npts + d], stored form
     struct Req { int kind, mode, npts, with_claim, derive1, ntab; size_t claim_slot, msg_slot, chal_slot, fin_slot, s[7]; };
-    enum { kRound = 0, kFinal = 1, kLink = 2 };
+    enum { kRound = 0, kFinal = 1, kLink = 2, kPair = 3 };
     std::vector<Req> reqs;                             // appended by the proving thread, consumed in order by the service thread
     std::mutex req_mu;
     size_t served = 0;                                 // service thread only
@@ -250,6 +250,36 @@ template <class F> struct DeviceRounds {
         hs[q.chal_slot] = r;
         mb_put(mb->chal, r);
     }
+    // basic sumcheck, one or two rounds from the four quarter sums of the current table (mle_kernels.cuh fold2_quarter_sums_kernel):
+    // round k sends (Q0 + Q1, Q2 + Q3); round k + 1, on the table folded by r_k, sends (Q0 + r_k (Q2 - Q0), Q1 + r_k (Q3 - Q1))
+    void serve_pair(const Req &q) {
+        Fe<F> Q[4];
+        for (int t = 0; t < 4; t++) Q[t] = mb_get(mb->ev + 12 * t);
+        const Fe<F> a0 = fe_add<F>(Q[0], Q[1]), a1 = fe_add<F>(Q[2], Q[3]);
+        if (q.with_claim) {
+            hs[q.claim_slot] = fe_add<F>(a0, a1);                              // prover.rs:28
+            htr->template append_be<F>(hs[q.claim_slot]);                      // :40-41
+        }
+        hs[q.msg_slot] = a0; hs[q.msg_slot + 1] = a1;
+        htr->template append_be<F>(a0);                                        // :52-55
+        htr->template append_be<F>(a1);
+        const Fe<F> r0 = htr->template random_challenge_as_field_element<F>(); // :58
+        hs[q.chal_slot] = r0;
+        running_claim = fe_add<F>(a0, fe_mul<F>(r0, fe_sub<F>(a1, a0)));
+        mb_put(mb->chal, r0);
+        if (q.s[0]) {                                                          // the next round as well: its table is the fold by r0 (:61-63)
+            const size_t per = q.s[1];
+            const Fe<F> b0 = fe_add<F>(Q[0], fe_mul<F>(r0, fe_sub<F>(Q[2], Q[0])));
+            const Fe<F> b1 = fe_add<F>(Q[1], fe_mul<F>(r0, fe_sub<F>(Q[3], Q[1])));
+            hs[q.msg_slot + per] = b0; hs[q.msg_slot + per + 1] = b1;
+            htr->template append_be<F>(b0);
+            htr->template append_be<F>(b1);
+            const Fe<F> r1 = htr->template random_challenge_as_field_element<F>();
+            hs[q.chal_slot + per] = r1;
+            running_claim = fe_add<F>(b0, fe_mul<F>(r1, fe_sub<F>(b1, b0)));
+            mb_put(mb->aux[0], r1);
+        }
+    }
     void serve_link(const Req &q) {                                            // gkr_protocol.rs:125-132
         const Fe<F> wb = hs[q.s[0]], wc = hs[q.s[1]];
         htr->template append_be<F>(wb);
@@ -292,6 +322,7 @@ template <class F> struct DeviceRounds {
                 if (!ok) { service_rc = ZK_E_HIP; break; }
             }
             if (q.kind == kRound) serve_round(q);
+            else if (q.kind == kPair) serve_pair(q);
             else if (q.kind == kLink) serve_link(q);
             else for (int k = 0; k < q.ntab; k++) hs[q.fin_slot + k] = mb_get(mb->fin + 12 * k);
             __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
@@ -334,6 +365,7 @@ template <class F> struct DeviceRounds {
         a.partials = partials; a.count = count; a.ctx = ctx(npts, mode); a.with_claim = with_claim; a.flags = derive_prev ? kDerive1 : 0;
         a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
         a.prev_msg_slot = msg_slot - per; a.prev_chal_slot = chal_slot - per;
+        a.chal_slot2 = ~(size_t)0;
         if (host_mode) {                                    // the derivation moves to the host with the rest of the step
             push_req(Req{kRound, mode, npts, with_claim, derive_prev, 0, claim_slot, msg_slot, chal_slot, 0, {0, 0, 0, 0, 0, 0, 0}});
             a.seq = nreq();
@@ -344,6 +376,21 @@ template <class F> struct DeviceRounds {
         const size_t cap = (size_t)kFinishBlock - (derive_prev ? 64 : 0);
         if (threads > cap) threads = cap;
         if (derive_prev) threads += 64;                   // the helper wave
+        sumcheck_finish_kernel<F><<<1, (int)threads, 0, cur_stream()>>>(a);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    // host mode, basic sumcheck: reduce the four quarter-sum partial lists (partials[t * count + block]) and run one (two = false) or
+    // two rounds on them; slots of round k: msg_slot, msg_slot + 1, chal_slot; of round k + 1: the same + per
+    int launch_pair(const void *partials, size_t count, int with_claim, size_t claim_slot, size_t msg_slot, size_t chal_slot, size_t per, bool two) {
+        FinishArgs a{};
+        a.partials = partials; a.count = count; a.ctx = ctx(4, 0); a.with_claim = with_claim; a.flags = 0;
+        a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
+        a.chal_slot2 = two ? chal_slot + per : ~(size_t)0;
+        push_req(Req{kPair, 0, 4, with_claim, 0, 0, claim_slot, msg_slot, chal_slot, 0, {two ? (size_t)1 : (size_t)0, per, 0, 0, 0, 0, 0}});
+        a.seq = nreq();
+        size_t threads = (count + 63) / 64 * 64;
+        if (threads > (size_t)kFinishBlock) threads = kFinishBlock;
         sumcheck_finish_kernel<F><<<1, (int)threads, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
@@ -436,6 +483,50 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
     // Every transcript step from here on runs on the device (dev_transcript.cuh): no host round trip per round.
     DeviceRounds<F> dr;
     ZK_TRY(dr.init(tr, std::vector<Fe<F>>(), 1 + 3 * (size_t)nvars));
+    if (dr.host_mode && len > kTailLen) {
+        // Two rounds per pass over the table (mle_kernels.cuh fold2_quarter_sums_kernel): the quarter sums of the current table carry
+        // rounds k and k + 1 (the host runs both transcript steps in one exchange), then one kernel folds both variables.
+        const void *cur = table->dptr;
+        void *dst = bufA.p, *other = bufB.p;
+        size_t cl = len;
+        unsigned round = 0;
+        int grid = reduce_grid_for(cl / 4);
+        segment_sums_kernel<F><<<grid, kBlock, 0, cur_stream()>>>(cur, cl / 4, 4, part);          // :74-89, by quarters
+        ZK_HIP(hipGetLastError());
+        size_t count = (size_t)grid;
+        for (;;) {
+            const bool two = cl > kTailLen;                            // else: one round from these sums, the tail takes over
+            ZK_TRY(dr.launch_pair(part, count, round == 0 ? 1 : 0, 0, 1 + 3 * (size_t)round, 3 + 3 * (size_t)round, 3, two));
+            if (!two) break;
+            const size_t n = cl / 4;                                   // :61-63 twice, fused with :50 of the two rounds after
+            size_t bpq = (n / 4 + kBlock - 1) / kBlock;
+            const size_t cap = (size_t)reduce_block_cap() / 4;
+            if (bpq > cap) bpq = cap;
+            if (bpq < 1) bpq = 1;
+            fold2_quarter_sums_kernel<F><<<(unsigned)(4 * bpq), kBlock, 0, cur_stream()>>>(cur, dst, n, dr.slot_ptr(3 + 3 * (size_t)round),
+                                                                                     dr.slot_ptr(3 + 3 * (size_t)(round + 1)), part);
+            ZK_HIP(hipGetLastError());
+            count = bpq;
+            cur = dst;
+            void *nx = other;
+            other = dst;
+            dst = nx;
+            cl = n;
+            round += 2;
+        }
+        SumPolyTables tabs{};
+        tabs.in[0] = cur;
+        ZK_TRY(dr.launch_tail(tabs, dst, other, 1, 1, cl, 0, round, 1, 3, 3, ~(size_t)0));
+        ZK_TRY(dr.collect(tr));
+        g_stats.ms_rounds = (float)(now_ms() - t1);
+        store_el<F>(claimed_sum, dr.slot(0));
+        for (unsigned rd = 0; rd < nvars; rd++) {
+            store_el<F>(round_polys + (size_t)(2 * rd) * L64, dr.slot(1 + 3 * (size_t)rd));
+            store_el<F>(round_polys + (size_t)(2 * rd + 1) * L64, dr.slot(2 + 3 * (size_t)rd));
+            if (challenges) store_el<F>(challenges + (size_t)rd * L64, dr.slot(3 + 3 * (size_t)rd));
+        }
+        return ZK_OK;
+    }
     {   // round-0 half sums (split_polynomial_and_sum_each :74-89); claimed sum = their sum (:28), absorbed first (:40-41)
         size_t seg = len / 2;
         int grid = reduce_grid_for(seg);
