@@ -220,7 +220,7 @@ int zk_sumcheck_gkr_verify(int field, const uint64_t *claimed_sum, const uint64_
 typedef struct zk_rounds zk_rounds;
 int zk_rounds_new(int field, int mode, size_t nprod, size_t nfac, size_t nrounds, zk_transcript *t, zk_rounds **out);
 int zk_rounds_free(zk_rounds *r);
-size_t zk_rounds_limbs_len(const zk_rounds *r);                     /* (nfac + 1) * (limbs32 + 1) words */
+size_t zk_rounds_limbs_len(const zk_rounds *r);                     /* capacity in words: (nfac + 1) * (limbs32 + 1); mode 0: 16 * (limbs32 + 1) */
 /* evaluations of the next round from the CURRENT tables (no fold) -> limbs_dev (device memory) */
 int zk_rounds_evals(zk_rounds *r, const zk_table *const *tables, uint64_t *limbs_dev);
 /* fold every table by the last absorbed round's challenge (device-resident) into `out`, and the next round's
@@ -231,6 +231,19 @@ int zk_rounds_absorb(zk_rounds *r, const uint64_t *limbs_dev);
 /* every remaining round in one launch on tables every rank holds in full (<= 2048 entries); the last absorbed
  * round's challenge folds first */
 int zk_rounds_tail(zk_rounds *r, const zk_table *const *tables);
+/* Basic sumcheck (mode 0) with the host-assisted transcript step: SEVERAL rounds per pass and per all-reduce
+ * (csrc/basic_multi.cuh).  The m rounds after a pass are the basic sumcheck on the table's 2^m segment sums (folding the top
+ * variable commutes with summing out the low ones), so: zk_rounds_multi_evals (2^m segment sums -> 2^m * (limbs32 + 1) words)
+ * -> all-reduce -> zk_rounds_multi_absorb (m transcript steps, one exchange) -> zk_rounds_multi_fold_evals (fold the k = m
+ * variables just absorbed, prover.rs:61-63 k times, and the 2^m_next segment sums of the output; m_next = 0: none) -> ...;
+ * once the global table has <= 2048 entries, gather it on every rank and zk_rounds_multi_tail runs every round left (none of
+ * them started) in one launch.  zk_rounds_multi_max = the largest m accepted, 0 when the handle cannot do this (mode 1, or the
+ * transcript step on the device): use the one-round sequence above then.  Same messages, same bytes absorbed. */
+unsigned zk_rounds_multi_max(const zk_rounds *r);
+int zk_rounds_multi_evals(zk_rounds *r, const zk_table *table, unsigned m, uint64_t *limbs_dev);
+int zk_rounds_multi_absorb(zk_rounds *r, const uint64_t *limbs_dev, unsigned m);
+int zk_rounds_multi_fold_evals(zk_rounds *r, const zk_table *in, zk_table *out, unsigned k, unsigned m_next, uint64_t *limbs_dev);
+int zk_rounds_multi_tail(zk_rounds *r, const zk_table *table);
 /* the single synchronisation: messages (nrounds x (nfac + 1) elements), challenges (nrounds), the claimed sum
  * (mode 0) and, after zk_rounds_tail, the nprod * nfac fully folded values; any pointer may be NULL */
 int zk_rounds_collect(zk_rounds *r, zk_transcript *t, uint64_t *claimed_sum, uint64_t *messages, uint64_t *challenges,

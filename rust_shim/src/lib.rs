@@ -89,6 +89,12 @@ pub mod ffi {
         pub fn zk_rounds_fold_evals(r: *mut c_void, inp: *const *const zk_table, out: *const *mut zk_table, limbs_dev: *mut u64) -> c_int;
         pub fn zk_rounds_absorb(r: *mut c_void, limbs_dev: *const u64) -> c_int;
         pub fn zk_rounds_tail(r: *mut c_void, tables: *const *const zk_table) -> c_int;
+        // basic sumcheck, several rounds per pass and per all-reduce (include/zkmle.h)
+        pub fn zk_rounds_multi_max(r: *const c_void) -> u32;
+        pub fn zk_rounds_multi_evals(r: *mut c_void, table: *const zk_table, m: u32, limbs_dev: *mut u64) -> c_int;
+        pub fn zk_rounds_multi_absorb(r: *mut c_void, limbs_dev: *const u64, m: u32) -> c_int;
+        pub fn zk_rounds_multi_fold_evals(r: *mut c_void, inp: *const zk_table, out: *mut zk_table, k: u32, m_next: u32, limbs_dev: *mut u64) -> c_int;
+        pub fn zk_rounds_multi_tail(r: *mut c_void, table: *const zk_table) -> c_int;
         pub fn zk_rounds_collect(r: *mut c_void, t: *mut zk_transcript, claimed: *mut u64, messages: *mut u64, challenges: *mut u64,
                                  final_values: *mut u64) -> c_int;
         pub fn zk_rounds_free(r: *mut c_void) -> c_int;

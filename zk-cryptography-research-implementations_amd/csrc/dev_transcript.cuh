@@ -162,7 +162,7 @@ struct HostMailbox {
     uint64_t cpu_seq;                   // last request the host answered
     uint64_t pad2[15];
     uint32_t chal[12];                  // the answer: the round's challenge
-    uint32_t aux[2][12];                // a layer link's answer: alpha, beta
+    uint32_t aux[3][12];                // a layer link's answer: alpha, beta; a multi-round exchange's challenges 1..3 (basic_multi.cuh)
     uint64_t aborted;                   // set by a kernel whose spin budget ran out (the host died or stalled > ~2 s): the kernel still ends
 };
 constexpr long long kMailboxSpinBudget = 2000000;       // polls of ~0.7-1.5 us each: 1.5-3 s
@@ -310,7 +310,6 @@ struct FinishArgs {
     size_t claim_slot, msg_slot, chal_slot;
     size_t prev_msg_slot, prev_chal_slot;   // kDerive1
     uint64_t seq;            // host-assisted step: the request number of this round
-    size_t chal_slot2;       // host-assisted pair of rounds (mle_kernels.cuh fold2_quarter_sums_kernel): the second challenge, ~0 = none
 };
 
 // One workgroup (64..1024 lanes, a multiple of 64).  Stage 1: every wave reduces its share of the partials, all npts
@@ -355,10 +354,7 @@ __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArg
     if (a.ctx.mb) {                                          // the host runs the transcript step; the challenge comes back through the mailbox
         mailbox_post<F>(a.ctx.mb, a.ctx.mb->ev, S.ev, npts, a.seq, lane);
         mailbox_wait(a.ctx.mb, a.seq, lane);
-        if (lane == 0) {
-            fe_store<F>(a.ctx.proof, a.chal_slot, mailbox_element<F>(a.ctx.mb->chal));
-            if (a.chal_slot2 != ~(size_t)0) fe_store<F>(a.ctx.proof, a.chal_slot2, mailbox_element<F>(a.ctx.mb->aux[0]));
-        }
+        if (lane == 0) fe_store<F>(a.ctx.proof, a.chal_slot, mailbox_element<F>(a.ctx.mb->chal));
         return;
     }
     uint32_t fill = a.ctx.sponge->fill;

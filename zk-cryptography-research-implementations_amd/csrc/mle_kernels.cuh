@@ -249,35 +249,6 @@ template <class F> __global__ void fold_half_sums_kernel(const void *__restrict_
     if (block_reduce_wide<F, 2>(sum, sh, tot)) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
 }
 
-// ---- two sumcheck rounds per pass (basic sumcheck, host-assisted transcript step) ----------------------------------------------
-// The round messages of the degree-1 sumcheck are LINEAR in the previous challenge: with the four quarter sums Q0..Q3 of a table,
-// round k sends (Q0 + Q1, Q2 + Q3) and round k + 1 sends (Q0 + r_k (Q2 - Q0), Q1 + r_k (Q3 - Q1)) -- no pass over the table between
-// them (prover.rs:50 of round k + 1 on the table folded at :61-63 of round k, same field elements).  So one kernel folds TWO variables
-// (out[j] = lo + r1 (hi - lo), lo = in[j] + r0 (in[j + 2 n] - in[j]), hi = in[j + n] + r0 (in[j + 3 n] - in[j + n]), n = outputs) and
-// leaves the quarter sums of its output for the next two rounds: 5/4 table lengths of traffic per two rounds instead of 9/4, and
-// one transcript exchange instead of two.  Blocks are assigned to one quarter of the output each (gridDim.x = 4 * blocks per quarter);
-// partials[quarter * bpq + block_in_quarter].
-template <class F> __global__ void fold2_quarter_sums_kernel(const void *__restrict__ in, void *__restrict__ out, size_t n,
-                                                            const void *__restrict__ r0p, const void *__restrict__ r1p,
-                                                            void *__restrict__ partials) {
-    __shared__ Wide<F> sh[kBlock / 64];
-    const unsigned bpq = gridDim.x / 4, quarter = blockIdx.x / bpq, bq = blockIdx.x % bpq;
-    const size_t qlen = n / 4, base = (size_t)quarter * qlen, stride = (size_t)bpq * blockDim.x;
-    const Multiplier<F> m0(fe_load<F>(r0p, 0)), m1(fe_load<F>(r1p, 0));
-    Wide<F> acc[1] = {wide_zero<F>()};
-    for (size_t t = (size_t)bq * blockDim.x + threadIdx.x; t < qlen; t += stride) {
-        const size_t j = base + t;
-        const Fe<F> a = fe_load<F>(in, j), b = fe_load<F>(in, j + n), c = fe_load<F>(in, j + 2 * n), d = fe_load<F>(in, j + 3 * n);
-        const Fe<F> lo = fe_add<F>(a, m0.times(fe_sub<F>(c, a)));
-        const Fe<F> hi = fe_add<F>(b, m0.times(fe_sub<F>(d, b)));
-        const Fe<F> o = fe_add<F>(lo, m1.times(fe_sub<F>(hi, lo)));
-        fe_store<F>(out, j, o);
-        wide_add_fe<F>(acc[0], o);
-    }
-    Fe<F> tot;
-    if (block_reduce_wide<F, 1>(acc, sh, tot)) fe_store<F>(partials, blockIdx.x, tot);
-}
-
 // ---- element-wise and tensor operations --------------------------------------------------------------
 enum { OP_SCALAR_MUL = 0, OP_ADD = 1, OP_SUB_SCALAR = 2, OP_TO_CANONICAL_BE = 3, OP_HI_MINUS_LO = 4 };
 

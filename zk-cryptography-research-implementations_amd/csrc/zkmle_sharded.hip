@@ -316,6 +316,49 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
     TableSet ping, pong;
     std::vector<const zk_table *> cur(tabs, tabs + ntab);
     bool absorbed = false;                                               // the evaluations of `cur` are in the transcript
+    const unsigned kmax = mode == 0 ? zk_rounds_multi_max(r) : 0u;
+    if (kmax > 0) {
+        // basic sumcheck, several rounds per pass and per all-reduce (basic_multi.cuh): the top-bit segments of the global table are
+        // the top-bit segments of every rank's shard, so the 2^m segment sums add up over the ranks like the two half sums do
+        const size_t W = (size_t)field_limbs64(field) * 2 + 1;
+        auto pass = [&](size_t global_len) {
+            const unsigned left = (unsigned)(ilog2(global_len) - ilog2(kTail));
+            return left < kmax ? left : kmax;
+        };
+        const zk_table *one = tabs[0];
+        if (L * G > kTail) {
+            ZK_TRY(ping.alloc(field, L / 2, 1));
+            ZK_TRY(pong.alloc(field, L / 4 ? L / 4 : 1, 1));
+            TableSet *dst = &ping, *other = &pong;
+            unsigned m = pass(L * G);
+            ZK_TRY(zk_rounds_multi_evals(r, one, m, lp));
+            for (;;) {
+                ZK_TRY(c->all_reduce_i64(lp, ((size_t)1 << m) * W));       // the only exchange of these m rounds, on the stream
+                ZK_TRY(zk_rounds_multi_absorb(r, lp, m));
+                const size_t n = L >> m;
+                const unsigned mn = n * G > kTail ? pass(n * G) : 0u;
+                ZK_TRY(zk_rounds_multi_fold_evals(r, one, dst->t[0], m, mn, lp));
+                one = dst->t[0];
+                TableSet *x = dst; dst = other; other = x;
+                L = n;
+                if (!mn) break;
+                m = mn;
+            }
+        }
+        if (G == 1) {
+            ZK_TRY(zk_rounds_multi_tail(r, one));
+            return zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+        }
+        DevBuf rcv, rep;                                                   // global index = j G + rank
+        ZK_TRY(rcv.alloc(G * L * esz));
+        ZK_TRY(rep.alloc(G * L * esz));
+        ZK_TRY(c->all_gather(one->dptr, rcv.p, L * esz));
+        interleave_kernel<<<grid_for(L * G * (esz / 16)), kBlock, 0, cur_stream()>>>((const uint4 *)rcv.p, (uint4 *)rep.p, 1, L, G, (int)(esz / 16));
+        ZK_HIP(hipGetLastError());
+        const zk_table view{field, L * G, rep.p, 0};
+        ZK_TRY(zk_rounds_multi_tail(r, &view));
+        return zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+    }
     if (L * G > kTail) {
         ZK_TRY(ping.alloc(field, L / 2, ntab));
         ZK_TRY(pong.alloc(field, L / 4 ? L / 4 : 1, ntab));

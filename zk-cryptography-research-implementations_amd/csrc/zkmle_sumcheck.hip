@@ -16,6 +16,7 @@
 
 #include "context.h"
 #include "dev_transcript.cuh"
+#include "basic_multi.cuh"
 #include "sumcheck_kernels.cuh"
 #include "transcript.h"
 #include "univariate.h"
@@ -161,7 +162,7 @@ template <class F> struct DeviceRounds {
     std::vector<Fe<F>> hs;                             // the proof slots, host copy
     std::vector<Fe<F>> hbasis;                         // basis[i * npts + d], stored form
     struct Req { int kind, mode, npts, with_claim, derive1, ntab; size_t claim_slot, msg_slot, chal_slot, fin_slot, s[7]; };
-    enum { kRound = 0, kFinal = 1, kLink = 2, kPair = 3 };
+    enum { kRound = 0, kFinal = 1, kLink = 2, kMulti = 3 };
     std::vector<Req> reqs;                             // appended by the proving thread, consumed in order by the service thread
     std::mutex req_mu;
     size_t served = 0;                                 // service thread only
@@ -250,34 +251,31 @@ template <class F> struct DeviceRounds {
         hs[q.chal_slot] = r;
         mb_put(mb->chal, r);
     }
-    // basic sumcheck, one or two rounds from the four quarter sums of the current table (mle_kernels.cuh fold2_quarter_sums_kernel):
-    // round k sends (Q0 + Q1, Q2 + Q3); round k + 1, on the table folded by r_k, sends (Q0 + r_k (Q2 - Q0), Q1 + r_k (Q3 - Q1))
-    void serve_pair(const Req &q) {
-        Fe<F> Q[4];
-        for (int t = 0; t < 4; t++) Q[t] = mb_get(mb->ev + 12 * t);
-        const Fe<F> a0 = fe_add<F>(Q[0], Q[1]), a1 = fe_add<F>(Q[2], Q[3]);
-        if (q.with_claim) {
-            hs[q.claim_slot] = fe_add<F>(a0, a1);                              // prover.rs:28
-            htr->template append_be<F>(hs[q.claim_slot]);                      // :40-41
-        }
-        hs[q.msg_slot] = a0; hs[q.msg_slot + 1] = a1;
-        htr->template append_be<F>(a0);                                        // :52-55
-        htr->template append_be<F>(a1);
-        const Fe<F> r0 = htr->template random_challenge_as_field_element<F>(); // :58
-        hs[q.chal_slot] = r0;
-        running_claim = fe_add<F>(a0, fe_mul<F>(r0, fe_sub<F>(a1, a0)));
-        mb_put(mb->chal, r0);
-        if (q.s[0]) {                                                          // the next round as well: its table is the fold by r0 (:61-63)
-            const size_t per = q.s[1];
-            const Fe<F> b0 = fe_add<F>(Q[0], fe_mul<F>(r0, fe_sub<F>(Q[2], Q[0])));
-            const Fe<F> b1 = fe_add<F>(Q[1], fe_mul<F>(r0, fe_sub<F>(Q[3], Q[1])));
-            hs[q.msg_slot + per] = b0; hs[q.msg_slot + per + 1] = b1;
-            htr->template append_be<F>(b0);
-            htr->template append_be<F>(b1);
-            const Fe<F> r1 = htr->template random_challenge_as_field_element<F>();
-            hs[q.chal_slot + per] = r1;
-            running_claim = fe_add<F>(b0, fe_mul<F>(r1, fe_sub<F>(b1, b0)));
-            mb_put(mb->aux[0], r1);
+    // basic sumcheck, q.npts rounds from the 2^npts segment sums of the current table (basic_multi.cuh): the basic sumcheck on the
+    // table of the sums, S -- round i sends its two half sums and folds its top variable by the challenge
+    void serve_multi(const Req &q) {
+        const int m = q.npts;
+        const size_t per = q.s[0];
+        size_t n = (size_t)1 << m;
+        Fe<F> S[1 << kMultiMax];
+        for (size_t t = 0; t < n; t++) S[t] = mb_get(mb->fin + 12 * t);
+        for (int i = 0; i < m; i++) {
+            const size_t half = n / 2;
+            Fe<F> a0 = S[0], a1 = S[half];                                     // prover.rs:50 (split_polynomial_and_sum_each :74-89)
+            for (size_t j = 1; j < half; j++) { a0 = fe_add<F>(a0, S[j]); a1 = fe_add<F>(a1, S[half + j]); }
+            if (i == 0 && q.with_claim) {
+                hs[q.claim_slot] = fe_add<F>(a0, a1);                          // :28
+                htr->template append_be<F>(hs[q.claim_slot]);                  // :40-41
+            }
+            hs[q.msg_slot + per * i] = a0; hs[q.msg_slot + per * i + 1] = a1;
+            htr->template append_be<F>(a0);                                    // :52-55
+            htr->template append_be<F>(a1);
+            const Fe<F> r = htr->template random_challenge_as_field_element<F>();   // :58
+            hs[q.chal_slot + per * i] = r;
+            running_claim = fe_add<F>(a0, fe_mul<F>(r, fe_sub<F>(a1, a0)));
+            mb_put(i == 0 ? mb->chal : mb->aux[i - 1], r);
+            for (size_t j = 0; j < half; j++) S[j] = fe_add<F>(S[j], fe_mul<F>(r, fe_sub<F>(S[half + j], S[j])));   // :61-63
+            n = half;
         }
     }
     void serve_link(const Req &q) {                                            // gkr_protocol.rs:125-132
@@ -322,7 +320,7 @@ template <class F> struct DeviceRounds {
                 if (!ok) { service_rc = ZK_E_HIP; break; }
             }
             if (q.kind == kRound) serve_round(q);
-            else if (q.kind == kPair) serve_pair(q);
+            else if (q.kind == kMulti) serve_multi(q);
             else if (q.kind == kLink) serve_link(q);
             else for (int k = 0; k < q.ntab; k++) hs[q.fin_slot + k] = mb_get(mb->fin + 12 * k);
             __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
@@ -365,7 +363,6 @@ template <class F> struct DeviceRounds {
         a.partials = partials; a.count = count; a.ctx = ctx(npts, mode); a.with_claim = with_claim; a.flags = derive_prev ? kDerive1 : 0;
         a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
         a.prev_msg_slot = msg_slot - per; a.prev_chal_slot = chal_slot - per;
-        a.chal_slot2 = ~(size_t)0;
         if (host_mode) {                                    // the derivation moves to the host with the rest of the step
             push_req(Req{kRound, mode, npts, with_claim, derive_prev, 0, claim_slot, msg_slot, chal_slot, 0, {0, 0, 0, 0, 0, 0, 0}});
             a.seq = nreq();
@@ -380,18 +377,36 @@ template <class F> struct DeviceRounds {
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
-    // host mode, basic sumcheck: reduce the four quarter-sum partial lists (partials[t * count + block]) and run one (two = false) or
-    // two rounds on them; slots of round k: msg_slot, msg_slot + 1, chal_slot; of round k + 1: the same + per
-    int launch_pair(const void *partials, size_t count, int with_claim, size_t claim_slot, size_t msg_slot, size_t chal_slot, size_t per, bool two) {
-        FinishArgs a{};
-        a.partials = partials; a.count = count; a.ctx = ctx(4, 0); a.with_claim = with_claim; a.flags = 0;
-        a.claim_slot = claim_slot; a.msg_slot = msg_slot; a.chal_slot = chal_slot;
-        a.chal_slot2 = two ? chal_slot + per : ~(size_t)0;
-        push_req(Req{kPair, 0, 4, with_claim, 0, 0, claim_slot, msg_slot, chal_slot, 0, {two ? (size_t)1 : (size_t)0, per, 0, 0, 0, 0, 0}});
-        a.seq = nreq();
-        size_t threads = (count + 63) / 64 * 64;
-        if (threads > (size_t)kFinishBlock) threads = kFinishBlock;
-        sumcheck_finish_kernel<F><<<1, (int)threads, 0, cur_stream()>>>(a);
+    // host mode, basic sumcheck (basic_multi.cuh): rounds round .. round + m - 1 from 2^m segment sums, given as partial lists
+    // (partials[seg * count + i]) or as all-reduced limbs; slots of round k: 1 + 3 k, 2 + 3 k (sums), 3 + 3 k (challenge), claim 0
+    int launch_multi(const void *partials, size_t count, const uint64_t *limbs_in, int m, size_t round) {
+        if (!host_mode || m < 1 || m > kMultiMax) return ZK_E_ARG;
+        push_req(Req{kMulti, 0, m, round == 0 ? 1 : 0, 0, 0, 0, 1 + 3 * round, 3 + 3 * round, 0, {3, 0, 0, 0, 0, 0, 0}});
+        MultiArgs a{partials, count, limbs_in, nullptr, m, mb_dev, (uint64_t)nreq(), proof(), 3 + 3 * round, 3};
+        multi_finish_kernel<F><<<1, 64 << m, 0, cur_stream()>>>(a);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    // the 2^m segment sums as limbs for the all-reduce of a sharded table (nothing posted)
+    int launch_multi_limbs(const void *partials, size_t count, int m, uint64_t *limbs_out) {
+        if (m < 1 || m > kMultiMax) return ZK_E_ARG;
+        MultiArgs a{partials, count, nullptr, limbs_out, m, nullptr, 0, nullptr, 0, 0};
+        multi_finish_kernel<F><<<1, 64 << m, 0, cur_stream()>>>(a);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    // host mode, basic sumcheck: every round of a table of <= kTailLen entries (rounds round ..), one launch (basic_multi.cuh)
+    int launch_basic_tail(const void *in, void *buf, size_t len, size_t round) {
+        if (!host_mode || len < 2 || len > kTailLen) return ZK_E_ARG;
+        BasicTailArgs a{in, buf, len, mb_dev, (uint64_t)nreq() + 1, proof(), 3 + 3 * round, 3};
+        size_t rd = round;
+        for (size_t cl = len; cl >= 2;) {
+            const int lg = (int)ilog2(cl), m = lg < kMultiMax ? lg : kMultiMax;
+            push_req(Req{kMulti, 0, m, rd == 0 ? 1 : 0, 0, 0, 0, 1 + 3 * rd, 3 + 3 * rd, 0, {3, 0, 0, 0, 0, 0, 0}});
+            rd += (size_t)m;
+            cl >>= m;
+        }
+        basic_tail_kernel<F><<<1, kTailBlock, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
@@ -456,6 +471,53 @@ template <class F> struct DeviceRounds {
     }
 };
 
+// ---- several rounds per pass (basic_multi.cuh) -------------------------------------------------------
+static int multi_kmax() {                                  // ZK_BASIC_ROUNDS_PER_PASS = 1..4 (default 4): for measurements
+    static const int v = [] {
+        const char *e = getenv("ZK_BASIC_ROUNDS_PER_PASS");
+        int k = e ? atoi(e) : kMultiMax;
+        return k < 1 ? 1 : k > kMultiMax ? kMultiMax : k;
+    }();
+    return v;
+}
+// rounds of the next pass over a table of `global_len` entries (> kTailLen): never past the length the tail takes over at
+static int multi_pass_rounds(size_t global_len) {
+    const int left = (int)ilog2(global_len) - (int)ilog2(kTailLen);
+    return left < multi_kmax() ? left : multi_kmax();
+}
+static unsigned multi_bps(size_t seglen, int m) {
+    size_t b = (seglen + kBlock - 1) / kBlock;
+    const size_t cap = (size_t)kMultiBlocks >> m;
+    return (unsigned)(b > cap ? cap : b < 1 ? 1 : b);
+}
+template <class F> int launch_seg_sums(const void *in, size_t len, int m, void *part, unsigned *bps_out) {
+    const size_t seglen = len >> m;
+    const unsigned bps = multi_bps(seglen, m);
+    seg_sums_kernel<F><<<bps << m, kBlock, 0, cur_stream()>>>(in, seglen, bps, part);
+    ZK_HIP(hipGetLastError());
+    *bps_out = bps;
+    return ZK_OK;
+}
+// fold the k variables whose challenges sit in rp[0 .. k) and leave 2^m_next segment sums of the output (m_next = 0: none)
+template <class F> int launch_foldk(const void *in, void *out, size_t n, int k, const void *const *rp, int m_next, void *part, unsigned *bps_out) {
+    FoldKArgs a{};
+    a.in = in; a.out = out; a.n = n;
+    for (int i = 0; i < k; i++) a.r[i] = rp[i];
+    a.partials = m_next ? part : nullptr;
+    a.bps = multi_bps(n >> m_next, m_next);
+    const unsigned grid = a.bps << m_next;
+    switch (k) {
+        case 1: foldk_seg_sums_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(a); break;
+        case 2: foldk_seg_sums_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(a); break;
+        case 3: foldk_seg_sums_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(a); break;
+        case 4: foldk_seg_sums_kernel<F, 4><<<grid, kBlock, 0, cur_stream()>>>(a); break;
+        default: return ZK_E_ARG;
+    }
+    ZK_HIP(hipGetLastError());
+    *bps_out = a.bps;
+    return ZK_OK;
+}
+
 // ---- basic sumcheck prover: prover.rs:22-71 ----------------------------------------------------------
 template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys, uint64_t *challenges) {
     const size_t esz = 4 * F::N, L64 = F::N / 2;
@@ -483,40 +545,32 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
     // Every transcript step from here on runs on the device (dev_transcript.cuh): no host round trip per round.
     DeviceRounds<F> dr;
     ZK_TRY(dr.init(tr, std::vector<Fe<F>>(), 1 + 3 * (size_t)nvars));
-    if (dr.host_mode && len > kTailLen) {
-        // Two rounds per pass over the table (mle_kernels.cuh fold2_quarter_sums_kernel): the quarter sums of the current table carry
-        // rounds k and k + 1 (the host runs both transcript steps in one exchange), then one kernel folds both variables.
+    if (dr.host_mode) {                                                // several rounds per pass over the table (basic_multi.cuh)
         const void *cur = table->dptr;
         void *dst = bufA.p, *other = bufB.p;
-        size_t cl = len;
-        unsigned round = 0;
-        int grid = reduce_grid_for(cl / 4);
-        segment_sums_kernel<F><<<grid, kBlock, 0, cur_stream()>>>(cur, cl / 4, 4, part);          // :74-89, by quarters
-        ZK_HIP(hipGetLastError());
-        size_t count = (size_t)grid;
-        for (;;) {
-            const bool two = cl > kTailLen;                            // else: one round from these sums, the tail takes over
-            ZK_TRY(dr.launch_pair(part, count, round == 0 ? 1 : 0, 0, 1 + 3 * (size_t)round, 3 + 3 * (size_t)round, 3, two));
-            if (!two) break;
-            const size_t n = cl / 4;                                   // :61-63 twice, fused with :50 of the two rounds after
-            size_t bpq = (n / 4 + kBlock - 1) / kBlock;
-            const size_t cap = (size_t)reduce_block_cap() / 4;
-            if (bpq > cap) bpq = cap;
-            if (bpq < 1) bpq = 1;
-            fold2_quarter_sums_kernel<F><<<(unsigned)(4 * bpq), kBlock, 0, cur_stream()>>>(cur, dst, n, dr.slot_ptr(3 + 3 * (size_t)round),
-                                                                                     dr.slot_ptr(3 + 3 * (size_t)(round + 1)), part);
-            ZK_HIP(hipGetLastError());
-            count = bpq;
-            cur = dst;
-            void *nx = other;
-            other = dst;
-            dst = nx;
-            cl = n;
-            round += 2;
+        size_t cl = len, round = 0;
+        if (cl > kTailLen) {
+            int m = multi_pass_rounds(cl);
+            unsigned bps;
+            ZK_TRY((launch_seg_sums<F>(cur, cl, m, part, &bps)));          // :74-89, by 2^m segments
+            for (;;) {
+                ZK_TRY(dr.launch_multi(part, bps, nullptr, m, round));     // rounds round .. round + m - 1 (:50-58), one exchange
+                const size_t n = cl >> m;
+                const int mn = n > kTailLen ? multi_pass_rounds(n) : 0;
+                const void *rp[kMultiMax];
+                for (int i = 0; i < m; i++) rp[i] = dr.slot_ptr(3 + 3 * (round + (size_t)i));
+                ZK_TRY((launch_foldk<F>(cur, dst, n, m, rp, mn, part, &bps)));   // :61-63 m times, fused with :74-89 of the next exchange
+                cur = dst;
+                void *nx = other;
+                other = dst;
+                dst = nx;
+                cl = n;
+                round += (size_t)m;
+                if (!mn) break;
+                m = mn;
+            }
         }
-        SumPolyTables tabs{};
-        tabs.in[0] = cur;
-        ZK_TRY(dr.launch_tail(tabs, dst, other, 1, 1, cl, 0, round, 1, 3, 3, ~(size_t)0));
+        ZK_TRY(dr.launch_basic_tail(cur, dst, cl, round));
         ZK_TRY(dr.collect(tr));
         g_stats.ms_rounds = (float)(now_ms() - t1);
         store_el<F>(claimed_sum, dr.slot(0));
@@ -815,6 +869,11 @@ struct RoundsBase {
     virtual int fold_evals(const zk_table *const *in, zk_table *const *out, uint64_t *limbs) = 0;
     virtual int absorb(const uint64_t *limbs) = 0;
     virtual int tail(const zk_table *const *tables) = 0;
+    virtual unsigned multi_max() const = 0;
+    virtual int multi_evals(const zk_table *table, unsigned m, uint64_t *limbs) = 0;
+    virtual int multi_absorb(const uint64_t *limbs, unsigned m) = 0;
+    virtual int multi_fold_evals(const zk_table *in, zk_table *out, unsigned k, unsigned m_next, uint64_t *limbs) = 0;
+    virtual int multi_tail(const zk_table *table) = 0;
     virtual int collect(zk_transcript *t, uint64_t *claimed_sum, uint64_t *messages, uint64_t *challenges, uint64_t *final_values) = 0;
 };
 
@@ -835,7 +894,7 @@ template <class F> struct RoundsImpl : RoundsBase {
         static const std::vector<Fe<F>> none;
         return dr.init(tr, mode == 1 ? sumcheck_basis<F>(npts) : none, fin_slot + ntab);
     }
-    size_t limbs_len() const override { return npts * (F::N + 1); }
+    size_t limbs_len() const override { return (mode == 0 ? (size_t)1 << kMultiMax : npts) * (F::N + 1); }
     int check_tables(const zk_table *const *t, size_t minlen) const {
         ZK_TRY(check_sumpoly(t, nprod, nfac));
         if (t[0]->field != F::ID || t[0]->len < minlen) return ZK_E_ARG;
@@ -919,6 +978,53 @@ template <class F> struct RoundsImpl : RoundsBase {
         ZK_TRY(dr.launch_tail(tabs, b0, b1, (int)nprod, (int)nfac, len, mode, round - 1, msg_base, chal_base, per, fin_slot));
         round = nrounds;
         tail_done = true;
+        return ZK_OK;
+    }
+    // ---- basic sumcheck, several rounds per pass (basic_multi.cuh): host-assisted transcript step only ----
+    unsigned multi_max() const override { return (mode == 0 && dr.host_mode) ? (unsigned)multi_kmax() : 0u; }
+    int multi_table(const zk_table *t, size_t minlen) const {
+        if (multi_max() == 0 || !t || t->field != F::ID || !is_pow2(t->len) || t->len < minlen) return ZK_E_ARG;
+        return ZK_OK;
+    }
+    int multi_evals(const zk_table *table, unsigned m, uint64_t *limbs) override {
+        ZK_TRY(multi_table(table, 2));
+        if (!limbs || m < 1 || m > multi_max() || ((size_t)1 << m) > table->len || round + m > nrounds) return ZK_E_ARG;
+        void *part;
+        ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
+        unsigned bps;
+        ZK_TRY((launch_seg_sums<F>(table->dptr, table->len, (int)m, part, &bps)));
+        return dr.launch_multi_limbs(part, bps, (int)m, limbs);
+    }
+    int multi_absorb(const uint64_t *limbs, unsigned m) override {
+        if (!limbs || m < 1 || m > multi_max() || round + m > nrounds) return ZK_E_ARG;
+        ZK_TRY(dr.launch_multi(nullptr, 0, limbs, (int)m, round));
+        round += m;
+        return ZK_OK;
+    }
+    int multi_fold_evals(const zk_table *in, zk_table *out, unsigned k, unsigned m_next, uint64_t *limbs) override {
+        ZK_TRY(multi_table(in, 2));
+        if (k < 1 || k > multi_max() || k > round || ((size_t)1 << k) > in->len || m_next > multi_max()) return ZK_E_ARG;
+        const size_t n = in->len >> k;
+        if (!out || out->field != F::ID || out->len < n || out->dptr == in->dptr) return ZK_E_ARG;
+        if (m_next && (!limbs || ((size_t)1 << m_next) > n)) return ZK_E_ARG;
+        void *part;
+        ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
+        const void *rp[kMultiMax];
+        for (unsigned i = 0; i < k; i++) rp[i] = dr.slot_ptr(chal_base + per * (round - k + i));
+        unsigned bps;
+        ZK_TRY((launch_foldk<F>(in->dptr, out->dptr, n, (int)k, rp, (int)m_next, part, &bps)));
+        out->len = n;
+        if (m_next) ZK_TRY(dr.launch_multi_limbs(part, bps, (int)m_next, limbs));
+        return ZK_OK;
+    }
+    // every remaining round on a table every rank holds in full (<= kTailLen entries); none of its rounds has started
+    int multi_tail(const zk_table *table) override {
+        ZK_TRY(multi_table(table, 2));
+        const size_t len = table->len;
+        if (len > kTailLen || round + ilog2(len) != nrounds) return ZK_E_ARG;
+        ZK_TRY(tailbuf.alloc((len / 2) * 4 * F::N));
+        ZK_TRY(dr.launch_basic_tail(table->dptr, tailbuf.p, len, round));
+        round = nrounds;
         return ZK_OK;
     }
     int collect(zk_transcript *t, uint64_t *claimed_sum, uint64_t *messages, uint64_t *challenges, uint64_t *final_values) override {
@@ -1223,6 +1329,23 @@ int zk_rounds_absorb(zk_rounds *r, const uint64_t *limbs_dev) {
 int zk_rounds_tail(zk_rounds *r, const zk_table *const *tables) {
     if (!r || !tables) return ZK_E_ARG;
     return r->impl->tail(tables);
+}
+unsigned zk_rounds_multi_max(const zk_rounds *r) { return r ? r->impl->multi_max() : 0u; }
+int zk_rounds_multi_evals(zk_rounds *r, const zk_table *table, unsigned m, uint64_t *limbs_dev) {
+    if (!r) return ZK_E_ARG;
+    return r->impl->multi_evals(table, m, limbs_dev);
+}
+int zk_rounds_multi_absorb(zk_rounds *r, const uint64_t *limbs_dev, unsigned m) {
+    if (!r) return ZK_E_ARG;
+    return r->impl->multi_absorb(limbs_dev, m);
+}
+int zk_rounds_multi_fold_evals(zk_rounds *r, const zk_table *in, zk_table *out, unsigned k, unsigned m_next, uint64_t *limbs_dev) {
+    if (!r) return ZK_E_ARG;
+    return r->impl->multi_fold_evals(in, out, k, m_next, limbs_dev);
+}
+int zk_rounds_multi_tail(zk_rounds *r, const zk_table *table) {
+    if (!r) return ZK_E_ARG;
+    return r->impl->multi_tail(table);
 }
 int zk_rounds_collect(zk_rounds *r, zk_transcript *t, uint64_t *claimed_sum, uint64_t *messages, uint64_t *challenges, uint64_t *final_values) {
     if (!r) return ZK_E_ARG;
