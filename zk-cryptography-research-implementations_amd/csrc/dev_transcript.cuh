@@ -164,7 +164,13 @@ struct HostMailbox {
     uint32_t chal[12];                  // the answer: the round's challenge
     uint32_t aux[3][12];                // a layer link's answer: alpha, beta; a multi-round exchange's challenges 1..3 (basic_multi.cuh)
     uint64_t aborted;                   // set by a kernel whose spin budget ran out (the host died or stalled > ~2 s): the kernel still ends
+    uint64_t pad3[7];
+    // A round's answer in ONE 64-byte line, so that the poll that sees it has the challenge already (a second read over PCIe costs ~1 us
+    // per round): dword 0 and dword 15 = the request number (low 32 bits), dwords 1 .. 12 = the challenge's limbs.  The host writes the
+    // limbs first and the two tags last; a tag in each 32-byte half keeps the test sound even if the line were fetched as two halves.
+    uint32_t ans[16];
 };
+static_assert(offsetof(HostMailbox, ans) % 64 == 0, "the answer line must not straddle two lines");
 constexpr long long kMailboxSpinBudget = 2000000;       // polls of ~0.7-1.5 us each: 1.5-3 s
 
 // wave 0, uniform: post `nel` elements from `src` (LDS) as request `seq`
@@ -187,6 +193,29 @@ __device__ __forceinline__ void mailbox_wait(HostMailbox *mb, uint64_t seq, unsi
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_system();
+}
+// wave 0, uniform: wait (bounded) for the answer line of request `seq` and return the challenge it carries (mailbox_wait + one read, fused)
+template <class F> __device__ __forceinline__ Fe<F> mailbox_wait_challenge(HostMailbox *mb, uint64_t seq, unsigned lane) {
+    const uint32_t tag = (uint32_t)seq;
+    uint32_t v = 0;
+    long long spins = 0;
+    for (;;) {
+        if (lane < 16) v = __hip_atomic_load(&mb->ans[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t ta = __builtin_amdgcn_readlane(v, 0), tb = __builtin_amdgcn_readlane(v, 15);
+        if (ta == tag && tb == tag) break;
+        int stop = 0;
+        if (lane == 0 && ((++spins & 63) == 0)) {            // now and then: has the host given up on this proof, or is the budget spent
+            if (spins > kMailboxSpinBudget || __atomic_load_n(&mb->aborted, __ATOMIC_RELAXED) != 0 ||
+                __atomic_load_n(&mb->cpu_seq, __ATOMIC_ACQUIRE) > seq + ((uint64_t)1 << 40)) { mb->aborted = seq; stop = 1; }
+        }
+        if (__builtin_amdgcn_readfirstlane(stop)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    Fe<F> e;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) e.l[i] = __builtin_amdgcn_readlane(v, 1 + i);
+    return e;
 }
 template <class F> __device__ __forceinline__ Fe<F> mailbox_element(const uint32_t *src) {
     Fe<F> e;
@@ -353,8 +382,8 @@ __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArg
     TS(1);
     if (a.ctx.mb) {                                          // the host runs the transcript step; the challenge comes back through the mailbox
         mailbox_post<F>(a.ctx.mb, a.ctx.mb->ev, S.ev, npts, a.seq, lane);
-        mailbox_wait(a.ctx.mb, a.seq, lane);
-        if (lane == 0) fe_store<F>(a.ctx.proof, a.chal_slot, mailbox_element<F>(a.ctx.mb->chal));
+        const Fe<F> r = mailbox_wait_challenge<F>(a.ctx.mb, a.seq, lane);
+        if (lane == 0) fe_store<F>(a.ctx.proof, a.chal_slot, r);
         return;
     }
     uint32_t fill = a.ctx.sponge->fill;
@@ -427,8 +456,8 @@ template <class F> __global__ void __launch_bounds__(128) limbs_finish_kernel(Li
     if (threadIdx.x >= 64) return;
     if (a.ctx.mb) {                                          // every rank's host runs the same transcript step on the summed evaluations
         mailbox_post<F>(a.ctx.mb, a.ctx.mb->ev, S.ev, a.ctx.npts, a.seq, lane);
-        mailbox_wait(a.ctx.mb, a.seq, lane);
-        if (lane == 0) fe_store<F>(a.ctx.proof, a.chal_slot, mailbox_element<F>(a.ctx.mb->chal));
+        const Fe<F> r = mailbox_wait_challenge<F>(a.ctx.mb, a.seq, lane);
+        if (lane == 0) fe_store<F>(a.ctx.proof, a.chal_slot, r);
         return;
     }
     uint32_t fill = a.ctx.sponge->fill;
@@ -512,7 +541,9 @@ struct TailArgs {
     size_t msg_base, chal_base, per;   // slots of round k: messages at msg_base + per k, challenge at chal_base + per k
     size_t fin_slot;         // ntab final values (only written when fin_slot != ~0)
     uint64_t seq0;           // host-assisted step: request number of the tail's first round; the final values go out as one more request
+    uint64_t *trace;         // ZK_TAIL_TRACE=1: 6 wall_clock64() stamps per round (measurement only), else nullptr
 };
+#define ZK_TAIL_STAMP(k) do { if (a.trace && tid == 0) a.trace[6 * j + (k)] = wall_clock64(); } while (0)
 
 template <class F, int NFAC>
 __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
@@ -533,6 +564,7 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
     while (cl >= 4) {                                        // fold by r AND evaluate the next round (sumcheck_kernels.cuh)
         const size_t q = cl / 4, ol = cl / 2;
         char *dst = (char *)a.buf[j & 1];
+        ZK_TAIL_STAMP(0);
         Wide<F> acc[NFAC + 1];
 #pragma unroll
         for (int t = 0; t <= NFAC; t++) acc[t] = wide_zero<F>();
@@ -620,15 +652,19 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
             }
         }
         Fe<F> tot;
+        ZK_TAIL_STAMP(1);
         if (block_reduce_wide<F, NFAC + 1>(acc, sh, tot)) S.ev[tid] = tot;
         __syncthreads();
+        ZK_TAIL_STAMP(2);
         round++;
         if (tid < 64) {
             if (mb) {                                        // transcript step on the host (HostMailbox)
                 mailbox_post<F>(mb, mb->ev, S.ev, NFAC + 1, seq, lane);
-                mailbox_wait(mb, seq, lane);
+                ZK_TAIL_STAMP(3);
+                const Fe<F> rn = mailbox_wait_challenge<F>(mb, seq, lane);
+                ZK_TAIL_STAMP(4);
                 if (lane == 0) {
-                    S.chal = mailbox_element<F>(mb->chal);
+                    S.chal = rn;
                     fe_store<F>(a.ctx.proof, a.chal_base + a.per * round, S.chal);
                 }
                 seq++;
@@ -637,6 +673,7 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
             }
         }
         __syncthreads();                                     // also orders this round's global stores before the next round's loads
+        ZK_TAIL_STAMP(5);
         r = S.chal;
         prev = dst;
         cl = ol;

@@ -32,6 +32,10 @@ struct Fr381 {
         constexpr uint32_t t[N] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu, 0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
         return t[i];
     }
+    static ZK_HD uint32_t red_k(int i) {   // 2^s R mod p, s = bitlen(p) - 1: mont(hi, red_k) = hi 2^s mod p (mle_kernels.cuh wide_reduce)
+        constexpr uint32_t t[N] = {0x7cfca71cu, 0x32667a63u, 0x21e35c08u, 0xc9a97675u, 0xa3ce7067u, 0x67e0272bu, 0xc70c9dbau, 0x58c473f4u};
+        return t[i];
+    }
     static constexpr uint32_t INV = 0xffffffffu;   // -p^-1 mod 2^32
 };
 struct Fq381 {
@@ -47,6 +51,10 @@ struct Fq381 {
     }
     static ZK_HD uint32_t r2(int i) {
         constexpr uint32_t t[N] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu, 0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+        return t[i];
+    }
+    static ZK_HD uint32_t red_k(int i) {   // 2^s R mod p, s = bitlen(p) - 1: mont(hi, red_k) = hi 2^s mod p (mle_kernels.cuh wide_reduce)
+        constexpr uint32_t t[N] = {0x41c2f6cau, 0xe20d11f3u, 0x3bc6904eu, 0xeb7dee69u, 0x9ca432ccu, 0x83290cc3u, 0xee4e48a3u, 0x4e671a9eu, 0xd633d08fu, 0xab5fc6a7u, 0x4b7c9801u, 0x17da78abu};
         return t[i];
     }
     static constexpr uint32_t INV = 0xfffcfffdu;
@@ -66,6 +74,10 @@ struct Bn254Fq {
         constexpr uint32_t t[N] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
         return t[i];
     }
+    static ZK_HD uint32_t red_k(int i) {   // 2^s R mod p, s = bitlen(p) - 1: mont(hi, red_k) = hi 2^s mod p (mle_kernels.cuh wide_reduce)
+        constexpr uint32_t t[N] = {0x4580fefau, 0x25e9b10eu, 0x6796d991u, 0x89ad1074u, 0xb1785b0au, 0x1fff6c96u, 0x957d3aa9u, 0x06e79dbcu};
+        return t[i];
+    }
     static constexpr uint32_t INV = 0xe4866389u;
 };
 struct Bn254Fr {
@@ -81,6 +93,10 @@ struct Bn254Fr {
     }
     static ZK_HD uint32_t r2(int i) {
         constexpr uint32_t t[N] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        return t[i];
+    }
+    static ZK_HD uint32_t red_k(int i) {   // 2^s R mod p, s = bitlen(p) - 1: mont(hi, red_k) = hi 2^s mod p (mle_kernels.cuh wide_reduce)
+        constexpr uint32_t t[N] = {0x33c42db5u, 0x8bf35b7bu, 0x4ba2b94eu, 0x4f86445fu, 0x7aa79b1cu, 0xe893391eu, 0x8c0ffc99u, 0x064f63e4u};
         return t[i];
     }
     static constexpr uint32_t INV = 0xefffffffu;

@@ -137,18 +137,17 @@ template <class F> __device__ __forceinline__ void wide_add(Wide<F> &w, const Wi
     for (int i = 0; i <= F::N; i++) w.l[i] = __builtin_addc(w.l[i], o.l[i], c, &c);
 }
 // S mod p.  Split S = lo + hi 2^s at s = bitlen(p) - 1, so lo < 2^s < p is already canonical and hi < 2^34 or so;
-// hi 2^s mod p = mont(mont(hi, R^2), 2^s) -- two products, taken once per workgroup.
+// hi 2^s mod p = mont(hi, 2^s R mod p) -- one product (on the latency path of every round), taken once per workgroup.
 template <class F> __device__ __forceinline__ Fe<F> wide_reduce(const Wide<F> &w) {
     constexpr int N = F::N;
     const int tb = 31 - __builtin_clz(F::p(N - 1));       // bit s within the top limb (1..31 for all four moduli)
-    Fe<F> lo, hi = fe_zero<F>(), pw = fe_zero<F>();
+    Fe<F> lo, hi = fe_zero<F>(), k;
 #pragma unroll
-    for (int i = 0; i < N; i++) lo.l[i] = w.l[i];
+    for (int i = 0; i < N; i++) { lo.l[i] = w.l[i]; k.l[i] = F::red_k(i); }
     lo.l[N - 1] &= (1u << tb) - 1u;
     hi.l[0] = (w.l[N - 1] >> tb) | (w.l[N] << (32 - tb));
     hi.l[1] = w.l[N] >> tb;
-    pw.l[N - 1] = 1u << tb;
-    return fe_add<F>(lo, fe_mul<F>(fe_from_canonical<F>(hi), pw));
+    return fe_add<F>(lo, fe_mul<F>(hi, k));
 }
 // Cross-lane steps use DPP (VALU rate; __shfl_down would be a ds_bpermute per limb and makes a many-wave reduction
 // LDS-crossbar bound).  Lanes without a source add zero.

@@ -323,6 +323,12 @@ template <class F> struct DeviceRounds {
             else if (q.kind == kMulti) serve_multi(q);
             else if (q.kind == kLink) serve_link(q);
             else for (int k = 0; k < q.ntab; k++) hs[q.fin_slot + k] = mb_get(mb->fin + 12 * k);
+            if (q.kind == kRound) {                              // the answer line: limbs first, the two tags last (dev_transcript.cuh)
+                const Fe<F> &r = hs[q.chal_slot];
+                for (int i = 0; i < F::N; i++) __atomic_store_n(&mb->ans[1 + i], r.l[i], __ATOMIC_RELAXED);
+                __atomic_store_n(&mb->ans[0], (uint32_t)seq, __ATOMIC_RELEASE);
+                __atomic_store_n(&mb->ans[15], (uint32_t)seq, __ATOMIC_RELEASE);
+            }
             __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
             served++;
         }
@@ -416,6 +422,12 @@ template <class F> struct DeviceRounds {
         TailArgs a{};
         a.tabs = tabs; a.buf[0] = buf0; a.buf[1] = buf1; a.nprod = nprod; a.ntab = nprod * nfac; a.len = len;
         a.ctx = ctx(nfac + 1, mode); a.round = round; a.msg_base = msg_base; a.chal_base = chal_base; a.per = per; a.fin_slot = fin_slot;
+        static const bool want_trace = [] { const char *e = getenv("ZK_TAIL_TRACE"); return e && e[0] == '1'; }();
+        if (want_trace) {                                   // measurement only: per-phase stamps of this tail, printed after the launch
+            ZK_TRY(tail_trace.alloc(6 * 16 * sizeof(uint64_t)));
+            ZK_HIP(hipMemsetAsync(tail_trace.p, 0, 6 * 16 * sizeof(uint64_t), cur_stream()));
+            a.trace = (uint64_t *)tail_trace.p;
+        }
         if (host_mode) {
             a.seq0 = nreq() + 1;
             size_t rd = round;
@@ -430,7 +442,25 @@ template <class F> struct DeviceRounds {
         else if (nfac == 2) sumcheck_tail_kernel<F, 2><<<1, kTailBlock, 0, cur_stream()>>>(a);
         else sumcheck_tail_kernel<F, 3><<<1, kTailBlock, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
+        if (a.trace && !host_mode) {                        // (host mode: printed by collect, after the service has answered)
+            ZK_HIP(hipStreamSynchronize(cur_stream()));
+            print_tail_trace(len);
+        }
+        traced_len = a.trace ? len : 0;
         return ZK_OK;
+    }
+    DevBuf tail_trace;
+    size_t traced_len = 0;
+    void print_tail_trace(size_t len) {
+        uint64_t st[6 * 16];
+        if (zk::memcpy_on_stream(st, tail_trace.p, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return;
+        static const char *names[5] = {"fold+terms", "reduce", "post", "wait", "sync"};
+        size_t cl = len;
+        for (int j = 0; cl >= 4 && j < 16; j++, cl /= 2) {
+            fprintf(stderr, "tail round %2d (len %4zu):", j, cl);
+            for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.2f us", names[k], (double)(st[6 * j + k + 1] - st[6 * j + k]) * 0.01);
+            fprintf(stderr, " | total %.2f us\n", (double)(st[6 * j + 5] - st[6 * j]) * 0.01);
+        }
     }
     // the layer link of a GKR proof in host mode: the host answers with alpha and beta once the two tails' final values are in
     int launch_link_host(size_t wb_src, size_t wc_src, size_t wb_slot, size_t wc_slot, size_t alpha_slot, size_t beta_slot, size_t claim_slot) {
@@ -447,6 +477,7 @@ template <class F> struct DeviceRounds {
             ZK_HIP(hipStreamSynchronize(cur_stream()));
             if (rc != ZK_OK) { set_last_error("host-assisted transcript step: the device did not post a round (aborted or stalled)"); return rc; }
             if (mb->aborted) { set_last_error("host-assisted transcript step: a kernel gave up waiting for the host"); return ZK_E_HIP; }
+            if (traced_len) print_tail_trace(traced_len);
             return ZK_OK;                                   // `tr` is the sponge the steps ran on
         }
         host.resize(bytes());
@@ -776,7 +807,10 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
     char *dst = (char *)bufA.p, *other = (char *)bufB.p;
     size_t cl = len;
     unsigned round = 0;
-    for (; cl > kTailLen; round++) {                                   // :37
+    // The one-workgroup tail takes over at 2048 entries, at 1024 for two or more two-factor products: its round on 2048 entries is a
+    // chain of 14 products per lane (28 us measured, tools ZK_TAIL_TRACE), the grid-wide round + finish launch pair takes 19.
+    const size_t tail_from = (nfac == 2 && nprod >= 2) ? kTailLen / 2 : kTailLen;
+    for (; cl > tail_from; round++) {                                  // :37
         const void *rp = dr.slot_ptr(s0 + per * round + npts);         // :55, on the device
         size_t ol = cl / 2, q = cl / 4;
         for (size_t k = 0; k < ntab; k++) tabs.out[k] = tables[k] ? dst + k * ol * esz : nullptr;
