@@ -316,7 +316,7 @@ def config5_leg(zk, comm, args, rank, world, collectives):
         cur = S.fe_add(field, rp[k, 0], m)
     ok = ok and np.array_equal(S.mle_evaluate(comm, table, ch), cur)
     out["sumcheck"] = {"what": f"Prover::prove rounds of the 2^{args.log_n} table ({rp.shape[0]} rounds), 2^{args.log_n}/{world} entries per rank, "
-                               "one all-reduce(SUM) of 18 int64 words per large round on the prover's stream, replicated one-launch tail, transcript step on each rank's host through the mailbox",
+                               "up to 4 rounds per pass over the shard: one all-reduce(SUM) of 2^m x 9 int64 words (m <= 4 rounds' segment sums) on the prover's stream per pass, replicated one-launch tail, transcript steps on each rank's host through the mailbox",
                        "ms_per_proof": dt * 1e3, "field_mul_per_s": (n_global - 1) / dt, "rounds": int(rp.shape[0]),
                        "collectives_per_proof": (nc1 - nc0) // 5, "bytes_received_per_proof": (rx1 - rx0) // 5,
                        "verifier_equations_hold": bool(ok)}
