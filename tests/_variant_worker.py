@@ -1,0 +1,68 @@
+"""Child process of tests/test_gpu_variants.py: the provers under an environment switch (read once per process), checked against the
+oracle.  Prints one JSON line {"checked": n, "mismatches": [...]}."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G                                                          # noqa: E402
+from oracle import oracle as O                                                       # noqa: E402
+
+
+def main():
+    zk = G.import_package()
+    from zkmle_amd import _lib
+    _lib.check(zk.lib().zk_init(0))
+
+    def rand_table(field, n, seed):
+        t = np.zeros((n, zk.limbs(field)), np.uint64)
+        assert zk.lib().zk_host_fill_random(field, seed, 0, n, t.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+        return t
+
+    bad, checked = [], 0
+    # basic sumcheck (prover.rs:35-71): sizes that take 0, 1 and several passes of 1..4 rounds before the tail
+    for field, logns in ((0, (1, 3, 11, 12, 13, 14, 15, 16, 18)), (1, (2, 12, 14, 15)), (3, (13, 17))):
+        for logn in logns:
+            table = rand_table(field, 1 << logn, 4000 + logn)
+            prover = zk.Prover.init(field, table)
+            proof = prover.prove()
+            cs, rp, ch = O.sumcheck_basic_prove(field, table)
+            ok = (np.array_equal(proof.initial_claimed_sum, cs) and np.array_equal(proof.round_univariate_polynomials.reshape(rp.shape), rp)
+                  and np.array_equal(prover.challenges.reshape(ch.shape), ch) and zk.Verifier.init().verify(proof) is True)
+            checked += 1
+            if not ok:
+                bad.append(["basic", field, logn])
+    # the same prover through the sharded entry point on a one-rank communicator (zk_rounds_* handle)
+    S = zk.sharded
+    comm = S.Comm()
+    for logn in (5, 12, 13, 16):
+        table = rand_table(0, 1 << logn, 4100 + logn)
+        cs, rp, ch = S.sumcheck_basic_prove_device(comm, S.GpuShard(zk.MultilinearPolynomial(0, table)), absorb_table=True)
+        ecs, erp, ech = O.sumcheck_basic_prove(0, table)
+        checked += 1
+        if not (np.array_equal(cs, ecs) and np.array_equal(rp.reshape(erp.shape), erp) and np.array_equal(ch.reshape(ech.shape), ech)):
+            bad.append(["sharded_basic", 0, logn])
+    comm.close()
+    # GKR sumcheck (sumcheck_gkr_protocol.rs:24-67)
+    MP = zk.MultilinearPolynomial
+    for field, (nprod, nfac, logn) in ((0, (2, 2, 5)), (0, (2, 2, 12)), (2, (3, 2, 13)), (0, (2, 3, 12)), (0, (2, 2, 16))):
+        n = 1 << logn
+        tabs = np.stack([np.stack([rand_table(field, n, 60 * p + f + logn) for f in range(nfac)]) for p in range(nprod)])
+        sp = zk.SumPolynomial([zk.ProductPolynomial([MP(field, t) for t in prod]) for prod in tabs])
+        claimed = O.vec_sum(field, O.sumpoly_reduce(field, tabs))
+        t_gpu, t_cpu = zk.Transcript(), O.Transcript()
+        result = zk.sumcheck.prove(sp, claimed, t_gpu)
+        co, chal = O.sumcheck_gkr_prove(field, tabs, claimed, t_cpu)
+        checked += 1
+        if not (np.array_equal(result.round_univariate_polynomials, co) and np.array_equal(result.random_challenges, chal)
+                and t_gpu.sample_random_challenge() == t_cpu.sample_random_challenge()):
+            bad.append(["gkr_sumcheck", field, nprod, nfac, logn])
+    print(json.dumps({"checked": checked, "mismatches": bad, "env": {k: v for k, v in os.environ.items() if k.startswith("ZK_")}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

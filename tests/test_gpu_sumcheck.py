@@ -69,8 +69,8 @@ def test_basic_sumcheck_derived_vectors(zk, derived_kats):
         assert zk.to_ints(f, prover.challenges)[: len(d["challenges"])] == [int(x, 16) for x in d["challenges"]]
 
 
-@pytest.mark.parametrize("field", [0, 2, 3])
-@pytest.mark.parametrize("logn", [0, 1, 2, 3, 7, 12, 16])
+@pytest.mark.parametrize("field", [0, 1, 2, 3])
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 7, 11, 12, 13, 14, 15, 16])    # 12..15: one pass of 1..4 rounds before the tail (basic_multi.cuh)
 def test_basic_sumcheck_random_vs_oracle(zk, field, logn):
     table = rand_table(zk, field, 1 << logn, 1000 + logn)
     prover = zk.Prover.init(field, table)

@@ -1,0 +1,25 @@
+"""The environment switches that select another code path for the same result -- the transcript step on the device
+(ZK_HOST_TRANSCRIPT=0) and the rounds-per-pass cap of the basic sumcheck (ZK_BASIC_ROUNDS_PER_PASS, csrc/basic_multi.cuh) -- are read
+once per process: each variant runs tests/_variant_worker.py in a child process and must reproduce the oracle's proofs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("env", [{"ZK_HOST_TRANSCRIPT": "0"}, {"ZK_BASIC_ROUNDS_PER_PASS": "1"}, {"ZK_BASIC_ROUNDS_PER_PASS": "2"},
+                                 {"ZK_BASIC_ROUNDS_PER_PASS": "3"}, {}], ids=["device_step", "k1", "k2", "k3", "default"])
+def test_variant_reproduces_oracle_proofs(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_variant_worker.py")], capture_output=True, text=True, env=e, timeout=600,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["checked"] >= 20
+    assert out["mismatches"] == [], out
