@@ -218,3 +218,16 @@ def test_full_size_fold_properties(zk, logn):
     point = rand_table(zk, field, logn, 99)
     point[0] = r
     assert np.array_equal(poly.evaluate(point), folded.evaluate(point[1:]))
+
+
+@pytest.mark.parametrize("field,logn", [(0, 16), (0, 17), (0, 19), (0, 20), (1, 16), (1, 18), (2, 17), (3, 18)])
+def test_evaluate_large_vs_oracle(zk, field, logn):
+    """evaluate (evaluation_form.rs:21-33) on tables large enough for the several-variables-per-pass kernel (zkmle_core.hip): full points
+    and every kind of shorter point (fewer values: element 0 of what is left)"""
+    MP = zk.MultilinearPolynomial
+    tab = rand_table(zk, field, 1 << logn, 9000 + logn)
+    poly = MP(field, tab)
+    point = rand_table(zk, field, logn, 9100 + logn)
+    for nv in (logn, logn - 1, logn - 3, 7, 5, 4, 3, 2, 1):
+        assert np.array_equal(poly.evaluate(point[:nv]), O.evaluate(field, tab, point[:nv])), (field, logn, nv)
+    assert np.array_equal(poly.evaluated_values, tab)            # the input is never folded in place

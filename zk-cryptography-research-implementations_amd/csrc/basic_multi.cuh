@@ -6,15 +6,14 @@
 // folded table are the fold of S.  So the m rounds that follow are the basic sumcheck on the 2^m-entry table S, exactly, and need no pass
 // over the big table: one kernel reduces 2^m segment sums, the host runs m transcript steps on them in ONE exchange (zkmle_sumcheck.hip
 // serve_multi) and answers with the m challenges, and one kernel folds the m variables at once and leaves the segment sums of its output
-// for the next exchange.  Per m rounds: (1 + 2^-m) table lengths of traffic instead of ~3, one exchange (and, sharded, one all-reduce of
+// (foldk_seg_sums_kernel, mle_kernels.cuh) for the next exchange.  Per m rounds: (1 + 2^-m) table lengths of traffic instead of ~3, one exchange (and, sharded, one all-reduce of
 // 2^m sums) instead of m.  Same field elements in the messages, same bytes absorbed, same challenges.
 #pragma once
 #include "dev_transcript.cuh"
 
 namespace zk {
 
-constexpr int kMultiMax = 4;            // rounds per exchange: 2^4 segment sums fit the mailbox's `fin` area, 4 challenges come back
-constexpr int kMultiBlocks = 2048;      // workgroups of a pass over a large table: (kMultiBlocks >> m) per segment
+// kMultiMax (mle_kernels.cuh) rounds per exchange: 2^4 segment sums fit the mailbox's `fin` area, 4 challenges come back
 
 // partials[seg * bps + b] = sum over block b's share of segment seg (gridDim.x = nseg * bps)
 template <class F>
@@ -26,125 +25,6 @@ __global__ void __launch_bounds__(kBlock) seg_sums_kernel(const void *__restrict
     for (size_t t = (size_t)bq * blockDim.x + threadIdx.x; t < seglen; t += stride) wide_add_fe<F>(acc[0], fe_load<F>(in, base + t));
     Fe<F> tot;
     if (block_reduce_wide<F, 1>(acc, sh, tot)) fe_store<F>(partials, blockIdx.x, tot);
-}
-
-// out[j] = the table folded by r[0] (top variable), r[1], ... r[K-1], j < n = len >> K: a binary tree over in[j + i n], i < 2^K, whose
-// level l pairs sub-trees 2^(K-1-l) entries apart (:61-63, K times).  Workgroups own one of the output's segments each (gridDim.x = nseg * bps)
-// and leave its partial sums when `partials` is given.
-struct FoldKArgs {
-    const void *in;
-    void *out;
-    size_t n;
-    const void *r[kMultiMax];    // the challenges, on the device (proof slots)
-    void *partials;              // nullptr: no sums (the tail takes over)
-    unsigned bps;
-};
-// depth-first over the tree (the folds commute: the value is the multilinear extension at (r[0], ..)): K + 1 live values instead of 2^K
-template <class F, int K, int L, int I> __device__ __forceinline__ Fe<F> fold_tree(const void *in, size_t j, size_t n, const Ufe<F> (&u)[K]) {
-    if constexpr (L == K) {
-        return fe_load<F>(in, j + (size_t)I * n);
-    } else {
-        const Fe<F> lo = fold_tree<F, K, L + 1, I>(in, j, n, u);
-        const Fe<F> hi = fold_tree<F, K, L + 1, I + (1 << (K - 1 - L))>(in, j, n, u);
-        return fe_add<F>(lo, fe_mul_u_pre<F>(u[L], fe_sub<F>(hi, lo)));
-    }
-}
-// The same value as a weighted sum: out[j] = sum_i eq_i(r) in[j + i n], eq_i = prod_l (bit_{K-1-l}(i) ? r[l] : 1 - r[l]) -- the multilinear
-// extension of the 2^K entries at (r[0], ..).  The tree costs 2^K - 1 full products (2 L^2 multiply-adds each); the weighted sum
-// accumulates the 2^K raw integer products (L^2 each) in 64-bit columns and pays ONE Montgomery reduction (L^2) per output: 1377 instead of
-// 2430 v_mad_u64_u32 for K = 4, which takes the kernel from the multiplier's roof back under the HBM roof.  Same field element (both are
-// the canonical residue of the same value).
-template <class F> struct RawAcc {
-    uint64_t c[2 * UParams<F>::L];
-};
-// acc += x * w (integers; limbs of both below 2^29): every column gains at most L 2^58
-template <class F> __device__ __forceinline__ void raw_mul_add(RawAcc<F> &acc, const Ufe<F> &x, const Ufe<F> &w) {
-    constexpr int L = UParams<F>::L;
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-#pragma unroll
-        for (int j = 0; j < L; j++) acc.c[i + j] += (uint64_t)x.l[j] * w.l[i];
-    }
-}
-template <class F> __device__ __forceinline__ void raw_normalize(RawAcc<F> &acc) {
-    constexpr int L = UParams<F>::L;
-#pragma unroll
-    for (int j = 0; j + 1 < 2 * L; j++) {
-        acc.c[j + 1] += acc.c[j] >> UB;
-        acc.c[j] &= UMASK;
-    }
-}
-// acc / 2^(29 L) mod p for normalized columns: below acc / 2^(29 L) + p
-template <class F> __device__ __forceinline__ Ufe<F> raw_mont_reduce(RawAcc<F> &acc) {
-    constexpr int L = UParams<F>::L;
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-        const uint32_t m = ((uint32_t)acc.c[i] * UParams<F>::INV) & UMASK;
-#pragma unroll
-        for (int j = 0; j < L; j++) acc.c[i + j] += (uint64_t)m * UParams<F>::p(j);
-        acc.c[i + 1] += acc.c[i] >> UB;                      // the low 29 bits of column i are now zero
-    }
-    Ufe<F> r;
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < L; j++) {
-        const uint64_t v = acc.c[L + j] + c;
-        r.l[j] = (uint32_t)v & UMASK;
-        c = v >> UB;
-    }
-    return r;
-}
-constexpr int kRawCarryEvery = 4;       // products between two normalizations: 4 L 2^58 + 2^30 < 2^64 for L <= 14
-
-template <class F, int K> __global__ void __launch_bounds__(kBlock) foldk_seg_sums_kernel(FoldKArgs a) {
-    __shared__ Wide<F> sh[kBlock / 64];
-    const unsigned nseg = gridDim.x / a.bps, seg = blockIdx.x / a.bps, bq = blockIdx.x % a.bps;
-    const size_t seglen = a.n / nseg, base = (size_t)seg * seglen, stride = (size_t)a.bps * blockDim.x;
-    Wide<F> acc[1] = {wide_zero<F>()};
-    if constexpr (K <= 2) {
-        Ufe<F> u[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) u[k] = u_from_limbs32<F>(fe_load<F>(a.r[k], 0));
-        for (size_t t = (size_t)bq * blockDim.x + threadIdx.x; t < seglen; t += stride) {
-            const size_t j = base + t;
-            const Fe<F> v = fold_tree<F, K, 0, 0>(a.in, j, a.n, u);
-            fe_store<F>(a.out, j, v);
-            wide_add_fe<F>(acc[0], v);
-        }
-    } else {
-        __shared__ Ufe<F> sw[1 << K];                        // eq_i in the scan's form (x 2^(29 L)), fully reduced
-        if (threadIdx.x < (1u << K)) {
-            Fe<F> w = fe_one<F>();
-#pragma unroll
-            for (int l = 0; l < K; l++) {
-                const Fe<F> r = fe_load<F>(a.r[l], 0);
-                w = fe_mul<F>(w, ((threadIdx.x >> (K - 1 - l)) & 1u) ? r : fe_sub<F>(fe_one<F>(), r));
-            }
-            sw[threadIdx.x] = u_reduce_once<F>(u_from_std<F>(w));
-        }
-        __syncthreads();
-        for (size_t t = (size_t)bq * blockDim.x + threadIdx.x; t < seglen; t += stride) {
-            const size_t j = base + t;
-            RawAcc<F> ra;
-#pragma unroll
-            for (int c = 0; c < 2 * UParams<F>::L; c++) ra.c[c] = 0;
-#pragma unroll 1
-            for (int i0 = 0; i0 < (1 << K); i0 += kRawCarryEvery) {
-                Fe<F> x[kRawCarryEvery];
-#pragma unroll
-                for (int i = 0; i < kRawCarryEvery; i++) x[i] = fe_load<F>(a.in, j + (size_t)(i0 + i) * a.n);
-#pragma unroll
-                for (int i = 0; i < kRawCarryEvery; i++) raw_mul_add<F>(ra, u_from_limbs32<F>(x[i]), sw[i0 + i]);
-                raw_normalize<F>(ra);
-            }
-            const Fe<F> v = u_to_limbs32<F>(u_reduce_once<F>(raw_mont_reduce<F>(ra)));
-            fe_store<F>(a.out, j, v);
-            wide_add_fe<F>(acc[0], v);
-        }
-    }
-    if (a.partials == nullptr) return;
-    Fe<F> tot;
-    if (block_reduce_wide<F, 1>(acc, sh, tot)) fe_store<F>(a.partials, blockIdx.x, tot);
 }
 
 // One workgroup of 2^m waves, wave w owns segment w: reduce its partials (or take the all-reduced limbs), then wave 0 posts the 2^m sums

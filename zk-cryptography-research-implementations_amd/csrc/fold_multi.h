@@ -1,0 +1,33 @@
+// fold_multi.h -- host-side launcher of foldk_seg_sums_kernel (mle_kernels.cuh): several variables of a table folded in one pass.
+#pragma once
+#include "context.h"
+#include "mle_kernels.cuh"
+
+namespace zk {
+
+inline unsigned multi_bps(size_t seglen, int m) {
+    size_t b = (seglen + kBlock - 1) / kBlock;
+    const size_t cap = (size_t)kMultiBlocks >> m;
+    return (unsigned)(b > cap ? cap : b < 1 ? 1 : b);
+}
+// fold the k variables whose values sit at rp[0 .. k) (device memory) and leave 2^m_next segment sums of the output (m_next = 0: none)
+template <class F> int launch_foldk(const void *in, void *out, size_t n, int k, const void *const *rp, int m_next, void *part, unsigned *bps_out) {
+    FoldKArgs a{};
+    a.in = in; a.out = out; a.n = n;
+    for (int i = 0; i < k; i++) a.r[i] = rp[i];
+    a.partials = m_next ? part : nullptr;
+    a.bps = multi_bps(n >> m_next, m_next);
+    const unsigned grid = a.bps << m_next;
+    switch (k) {
+        case 1: foldk_seg_sums_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(a); break;
+        case 2: foldk_seg_sums_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(a); break;
+        case 3: foldk_seg_sums_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(a); break;
+        case 4: foldk_seg_sums_kernel<F, 4><<<grid, kBlock, 0, cur_stream()>>>(a); break;
+        default: return ZK_E_ARG;
+    }
+    ZK_HIP(hipGetLastError());
+    if (bps_out) *bps_out = a.bps;
+    return ZK_OK;
+}
+
+}  // namespace zk

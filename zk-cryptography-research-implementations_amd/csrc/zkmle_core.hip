@@ -7,6 +7,7 @@
 
 #include "context.h"
 #include "mle_kernels.cuh"
+#include "fold_multi.h"
 
 namespace zk {
 
@@ -482,7 +483,17 @@ int zk_mle_evaluate(const zk_table *t, const uint64_t *values, size_t nvalues, u
     if (t->len >= 4) rc = table_alloc_pooled(t->field, t->len / 4, &b);
     const zk_table *cur = t;
     zk_table *dst = a, *other = b;
-    for (size_t i = 0; i < nvalues && rc == ZK_OK; i++) {
+    // Large tables: up to kMultiMax variables per pass (foldk_seg_sums_kernel: the K folds as one lazily reduced weighted sum -- the
+    // same field element as K successive folds, 1 + 2^-K table lengths of traffic per K variables instead of 3 (1 - 2^-K)).  The values
+    // are read from device memory by that kernel.
+    struct PoolBuf { void *p = nullptr; ~PoolBuf() { pool_free(p); } int alloc(size_t bytes) { return pool_alloc(bytes, &p); } } vdev;
+    const size_t kMultiFrom = (size_t)1 << 16;
+    if (rc == ZK_OK && nvalues >= 2 && t->len >= kMultiFrom) {
+        rc = vdev.alloc(nvalues * esz);
+        if (rc == ZK_OK && zk::memcpy_on_stream(vdev.p, values, nvalues * esz, hipMemcpyHostToDevice) != hipSuccess) rc = ZK_E_HIP;
+    }
+    size_t i = 0;
+    while (rc == ZK_OK && i < nvalues) {
         if (cur->len <= 2 * (size_t)kEvalTailBlock && nvalues - i <= (size_t)kEvalTailVars) {   // the rest in one launch
             const int nv = (int)(nvalues - i);
             ZK_DISPATCH_FIELD(t->field, {
@@ -495,8 +506,19 @@ int zk_mle_evaluate(const zk_table *t, const uint64_t *values, size_t nvalues, u
             cur = dst;
             break;
         }
-        dst->len = cur->len / 2;
-        rc = zk_mle_fold_ptr(t->field, cur->dptr, cur->len, 0, values + i * limbs, dst->dptr, nullptr);
+        size_t k = nvalues - i < (size_t)kMultiMax ? nvalues - i : (size_t)kMultiMax;
+        while (k > 1 && (cur->len >> k) < 2 * (size_t)kEvalTailBlock) k--;                       // leave the tail its share
+        if (vdev.p && k >= 2 && cur->len >= kMultiFrom) {
+            const void *rp[kMultiMax];
+            for (size_t j = 0; j < k; j++) rp[j] = (const char *)vdev.p + (i + j) * esz;
+            dst->len = cur->len >> k;
+            ZK_DISPATCH_FIELD(t->field, { rc = (launch_foldk<F>(cur->dptr, dst->dptr, dst->len, (int)k, rp, 0, nullptr, nullptr)); });
+            i += k;
+        } else {
+            dst->len = cur->len / 2;
+            rc = zk_mle_fold_ptr(t->field, cur->dptr, cur->len, 0, values + i * limbs, dst->dptr, nullptr);
+            i += 1;
+        }
         cur = dst;
         zk_table *nx = other;
         other = dst;

@@ -17,6 +17,7 @@
 #include "context.h"
 #include "dev_transcript.cuh"
 #include "basic_multi.cuh"
+#include "fold_multi.h"
 #include "sumcheck_kernels.cuh"
 #include "transcript.h"
 #include "univariate.h"
@@ -516,11 +517,6 @@ static int multi_pass_rounds(size_t global_len) {
     const int left = (int)ilog2(global_len) - (int)ilog2(kTailLen);
     return left < multi_kmax() ? left : multi_kmax();
 }
-static unsigned multi_bps(size_t seglen, int m) {
-    size_t b = (seglen + kBlock - 1) / kBlock;
-    const size_t cap = (size_t)kMultiBlocks >> m;
-    return (unsigned)(b > cap ? cap : b < 1 ? 1 : b);
-}
 template <class F> int launch_seg_sums(const void *in, size_t len, int m, void *part, unsigned *bps_out) {
     const size_t seglen = len >> m;
     const unsigned bps = multi_bps(seglen, m);
@@ -529,26 +525,6 @@ template <class F> int launch_seg_sums(const void *in, size_t len, int m, void *
     *bps_out = bps;
     return ZK_OK;
 }
-// fold the k variables whose challenges sit in rp[0 .. k) and leave 2^m_next segment sums of the output (m_next = 0: none)
-template <class F> int launch_foldk(const void *in, void *out, size_t n, int k, const void *const *rp, int m_next, void *part, unsigned *bps_out) {
-    FoldKArgs a{};
-    a.in = in; a.out = out; a.n = n;
-    for (int i = 0; i < k; i++) a.r[i] = rp[i];
-    a.partials = m_next ? part : nullptr;
-    a.bps = multi_bps(n >> m_next, m_next);
-    const unsigned grid = a.bps << m_next;
-    switch (k) {
-        case 1: foldk_seg_sums_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(a); break;
-        case 2: foldk_seg_sums_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(a); break;
-        case 3: foldk_seg_sums_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(a); break;
-        case 4: foldk_seg_sums_kernel<F, 4><<<grid, kBlock, 0, cur_stream()>>>(a); break;
-        default: return ZK_E_ARG;
-    }
-    ZK_HIP(hipGetLastError());
-    *bps_out = a.bps;
-    return ZK_OK;
-}
-
 // ---- basic sumcheck prover: prover.rs:22-71 ----------------------------------------------------------
 template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys, uint64_t *challenges) {
     const size_t esz = 4 * F::N, L64 = F::N / 2;
