@@ -571,9 +571,13 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
         // A lane's share of a round is a chain of products (14 for two products of two factors) and the round lasts as long as
         // that chain, so idle lanes take over parts of it once the table is short: one lane per (pair index, product) while
         // q * nprod lanes exist, one lane per (pair index, table) -- the factors then meet through LDS -- while q * ntab <= kTailSplit.
+        // Shortest tables: one lane per (pair index, table, lo | hi) for the folds, then one per (pair index, product, point) for the terms:
+        // ONE product per lane and phase.  A round this short is a lone wave's instruction stream (~8 cycles per instruction, ~250 per
+        // product), and the per-table split makes a wave issue 2 products for the folds plus 2 + 1 (divergent) for the terms.
         int split = 0;
         if constexpr (NFAC == 2) {
-            if (q * (size_t)a.ntab <= (size_t)kTailSplit) split = 2;
+            if (2 * q * (size_t)a.ntab <= (size_t)kTailBlock) split = 3;
+            else if (q * (size_t)a.ntab <= (size_t)kTailSplit) split = 2;
             else if (q * (size_t)a.nprod <= (size_t)kTailBlock) split = 1;
         }
         if (split == 0) {
@@ -597,6 +601,7 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                 }
             }
         } else if constexpr (NFAC == 2) {
+            __shared__ Fe<F> exch[2 * kTailSplit];               // split 2: (lo, hi) of table k at pair index i: exch[2 (k q + i) ..]; split 3: exch[(2 k + h) q + i]
             const unsigned qlog = 31u - (unsigned)__builtin_clz((unsigned)q);
             const unsigned i = tid & ((unsigned)q - 1u), grp = tid >> qlog;      // pair index, product (split 1) or table (split 2)
             const Multiplier<F> mr(r);
@@ -618,8 +623,32 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                     }
                     accumulate_terms<F, NFAC>(lo, hi, acc);
                 }
+            } else if (split == 3) {
+                if (grp < 2u * (unsigned)a.ntab) {                   // role = (table, half): entry i + h q of the folded table
+                    const unsigned k = grp >> 1, h = grp & 1u;
+                    Fe<F> v;
+                    if (a.tabs.in[k] == nullptr) {
+                        v = const_factor<F>(a.tabs, (int)(k >> 1));
+                    } else {
+                        const void *src = prev ? (const void *)(prev + (size_t)k * cl * esz) : a.tabs.in[k];
+                        const Fe<F> x = fe_load<F>(src, i + h * q), y = fe_load<F>(src, i + h * q + 2 * q);
+                        v = fe_add<F>(x, mr.times(fe_sub<F>(y, x)));
+                        fe_store<F>(dst + (size_t)k * ol * esz, i + h * q, v);
+                    }
+                    exch[grp * (unsigned)q + i] = v;
+                }
+                __syncthreads();
+                if (grp < 3u * (unsigned)a.nprod) {                  // role = (product, point)
+                    const unsigned p = grp / 3u, t = grp - 3u * p, b0 = 4u * p * (unsigned)q + i;
+                    const Fe<F> lo = exch[b0], hi = exch[b0 + (unsigned)q], lo2 = exch[b0 + 2u * (unsigned)q], hi2 = exch[b0 + 3u * (unsigned)q];
+                    const Fe<F> x = t == 0 ? lo : t == 1 ? hi : fe_add<F>(hi, fe_sub<F>(hi, lo));
+                    const Fe<F> y = t == 0 ? lo2 : t == 1 ? hi2 : fe_add<F>(hi2, fe_sub<F>(hi2, lo2));
+                    const Fe<F> pr = fe_mul<F>(x, y);
+                    if (t == 0) wide_add_fe<F>(acc[0], pr);
+                    else if (t == 1) wide_add_fe<F>(acc[1], pr);
+                    else wide_add_fe<F>(acc[2], pr);
+                }
             } else {
-                __shared__ Fe<F> exch[2 * kTailSplit];           // (lo, hi) of table k at pair index i: exch[2 (k q + i) ..]
                 const bool act = grp < (unsigned)a.ntab;
                 Fe<F> lo = fe_zero<F>(), hi = fe_zero<F>();
                 if (act) {
@@ -653,7 +682,9 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
         }
         Fe<F> tot;
         ZK_TAIL_STAMP(1);
-        if (block_reduce_wide<F, NFAC + 1>(acc, sh, tot)) S.ev[tid] = tot;
+        // waves past the last lane with a term hold zeros
+        const size_t term_lanes = split == 3 ? 3 * q * (size_t)a.nprod : split == 2 ? q * (size_t)a.ntab : split == 1 ? q * (size_t)a.nprod : q;
+        if (block_reduce_wide<F, NFAC + 1>(acc, sh, tot, (int)((term_lanes + 63) / 64))) S.ev[tid] = tot;
         __syncthreads();
         ZK_TAIL_STAMP(2);
         round++;

@@ -181,17 +181,22 @@ template <class F, int K> __device__ __forceinline__ void wave_reduce_wide(Wide<
 // Workgroup sums of K lazily accumulated values.  `sh` holds K * (blockDim.x / 64) Wides.  Returns true in the K lanes
 // (threads 0..K-1) that hold a result: thread k gets sum k, fully reduced.  Contains one __syncthreads; callers that
 // reuse `sh` afterwards must synchronise again.
-template <class F, int K> __device__ __forceinline__ bool block_reduce_wide(Wide<F> (&v)[K], Wide<F> *sh, Fe<F> &out) {
-    wave_reduce_wide<F, K>(v);
+// `active_waves` (uniform, >= 1): only the first that many waves hold anything but zeros; the others skip their share of the work, which
+// also frees issue slots on the SIMDs they share with the waves that matter (the one-workgroup tail of a sumcheck on short tables).
+template <class F, int K> __device__ __forceinline__ bool block_reduce_wide(Wide<F> (&v)[K], Wide<F> *sh, Fe<F> &out, int active_waves = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (lane == 63) {
+    const int na = (active_waves > 0 && active_waves < nw) ? active_waves : nw;
+    if (wave < na) {
+        wave_reduce_wide<F, K>(v);
+        if (lane == 63) {
 #pragma unroll
-        for (int k = 0; k < K; k++) sh[k * nw + wave] = v[k];
+            for (int k = 0; k < K; k++) sh[k * nw + wave] = v[k];
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x >= K) return false;
     Wide<F> tot = sh[threadIdx.x * nw];
-    for (int w = 1; w < nw; w++) wide_add<F>(tot, sh[threadIdx.x * nw + w]);
+    for (int w = 1; w < na; w++) wide_add<F>(tot, sh[threadIdx.x * nw + w]);
     out = wide_reduce<F>(tot);
     return true;
 }

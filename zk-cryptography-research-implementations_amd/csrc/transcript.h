@@ -100,7 +100,14 @@ class Keccak256 {
 
     void lane_xor(size_t byte_pos, uint8_t v) { a_[byte_pos / 8] ^= (uint64_t)v << (8 * (byte_pos % 8)); }
     void xor_in(const uint8_t *d, size_t n) {
-        for (size_t i = 0; i < n; i++) lane_xor(fill_ + i, d[i]);
+        size_t i = 0;
+        if (fill_ % 8 == 0)                                  // whole lanes at once (round messages are 32-byte elements on a 32-byte grid)
+            for (; i + 8 <= n; i += 8) {
+                uint64_t w;
+                memcpy(&w, d + i, 8);
+                a_[(fill_ + i) / 8] ^= w;                    // little-endian hosts (see update)
+            }
+        for (; i < n; i++) lane_xor(fill_ + i, d[i]);
         fill_ += n;
     }
     void permute() { keccak_f1600(a_); }

@@ -518,20 +518,15 @@ int zk_sharded_mle_evaluate(zk_comm *c, const zk_table *shard, const uint64_t *v
     if (nvalues != m + k) return ZK_E_RANGE;
     const int field = shard->field;
     const size_t L64 = (size_t)field_limbs64(field), esz = L64 * 8;
-    TableSet tmp;
-    const zk_table *cur = shard;
-    if (m > 0) {
-        ZK_TRY(tmp.alloc(field, shard->len / 2, 1));
-        ZK_TRY(tmp.alloc(field, shard->len / 4 ? shard->len / 4 : 1, 1));
-        for (size_t i = 0; i < m; i++) {                                  // evaluation_form.rs:27-29, local: variable 0 pairs equal low bits
-            zk_table *dst = tmp.t[i & 1];
-            ZK_TRY(zk_mle_fold(cur, 0, values + i * L64, dst, nullptr));
-            cur = dst;
-        }
-    }
-    DevBuf all;
+    // evaluation_form.rs:27-29, local: variable 0 pairs equal low bits, so the first m values fold the shard down to this rank's entry
+    // of the G-entry table of what is left (zk_mle_evaluate: up to four variables per pass)
+    uint64_t mine[6];
+    ZK_TRY(zk_mle_evaluate(shard, values, m, mine));
+    DevBuf snd, all;
+    ZK_TRY(snd.alloc(esz));
     ZK_TRY(all.alloc(G * esz));
-    ZK_TRY(c->all_gather(cur->dptr, all.p, esz));                         // entry g = rank g's value = global index g
+    ZK_HIP(memcpy_on_stream(snd.p, mine, esz, hipMemcpyHostToDevice));
+    ZK_TRY(c->all_gather(snd.p, all.p, esz));                             // entry g = rank g's value = global index g
     zk_table rep{field, G, all.p, 0};
     return zk_mle_evaluate(&rep, values + m * L64, k, out);
 }

@@ -222,7 +222,17 @@ template <class F> struct DeviceRounds {
     static void mb_put(uint32_t *dst, const Fe<F> &e) {
         for (int i = 0; i < F::N; i++) __atomic_store_n(dst + i, e.l[i], __ATOMIC_RELAXED);
     }
-    void serve_round(const Req &q) {
+    // the answer of a round: the challenge, in the polled line (limbs first, the two tags last: dev_transcript.cuh) and in `chal`
+    void publish_challenge(uint64_t seq, const Fe<F> &r) {
+        mb_put(mb->chal, r);
+        for (int i = 0; i < F::N; i++) __atomic_store_n(&mb->ans[1 + i], r.l[i], __ATOMIC_RELAXED);
+        __atomic_store_n(&mb->ans[0], (uint32_t)seq, __ATOMIC_RELEASE);
+        __atomic_store_n(&mb->ans[15], (uint32_t)seq, __ATOMIC_RELEASE);
+        __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
+    }
+    // The kernel that posted the evaluations is spinning until the challenge is back, so only what the challenge depends on runs before
+    // the answer goes out; the proof's copy of the message and the running claim are worked out while the GPU is already in the next round.
+    void serve_round(const Req &q, uint64_t seq) {
         Fe<F> ev[kMaxPts];
         for (int t = 0; t < q.npts; t++) ev[t] = mb_get(mb->ev + 12 * t);
         if (q.derive1) ev[1] = fe_sub<F>(running_claim, ev[0]);                // the producer skipped the point 1 (dev_transcript.cuh kDerive1)
@@ -232,25 +242,35 @@ template <class F> struct DeviceRounds {
                 hs[q.claim_slot] = fe_add<F>(ev[0], ev[1]);                    // :28
                 htr->template append_be<F>(hs[q.claim_slot]);                  // :40-41
             }
-            for (int t = 0; t < q.npts; t++) { hs[q.msg_slot + t] = ev[t]; htr->template append_be<F>(ev[t]); }
+            for (int t = 0; t < q.npts; t++) htr->template append_be<F>(ev[t]);
             r = htr->template random_challenge_as_field_element<F>();
+            publish_challenge(seq, r);
+            for (int t = 0; t < q.npts; t++) hs[q.msg_slot + t] = ev[t];
             running_claim = fe_add<F>(ev[0], fe_mul<F>(r, fe_sub<F>(ev[1], ev[0])));
         } else {                                                               // sumcheck_gkr_protocol.rs:46-55: Lagrange coefficients, little-endian
             if (q.with_claim) htr->template append_be<F>(hs[q.claim_slot]);    // :35
+            // coefficient d as the canonical integer straight away: evaluations (stored form) x the basis as canonical integers
+            const size_t n2 = (size_t)q.npts * q.npts;
+            uint8_t bytes[kMaxPts * 4 * F::N];
+            for (int d = 0; d < q.npts; d++) {
+                Fe<F> cc = fe_mul<F>(ev[0], hbasis[n2 + d]);
+                for (int i = 1; i < q.npts; i++) cc = fe_add<F>(cc, fe_mul<F>(ev[i], hbasis[n2 + (size_t)i * q.npts + d]));
+                memcpy(bytes + (size_t)d * 4 * F::N, cc.l, 4 * F::N);          // univariate_to_bytes :145-150: little-endian limbs as they lie (LE host)
+            }
+            htr->append(bytes, (size_t)q.npts * 4 * F::N);
+            r = htr->template random_challenge_as_field_element<F>();
+            publish_challenge(seq, r);
             Fe<F> c[kMaxPts];
             for (int d = 0; d < q.npts; d++) {
                 c[d] = fe_mul<F>(ev[0], hbasis[d]);
                 for (int i = 1; i < q.npts; i++) c[d] = fe_add<F>(c[d], fe_mul<F>(ev[i], hbasis[(size_t)i * q.npts + d]));
                 hs[q.msg_slot + d] = c[d];
             }
-            for (int d = 0; d < q.npts; d++) htr->template append_le<F>(c[d]);
-            r = htr->template random_challenge_as_field_element<F>();
             Fe<F> acc = c[q.npts - 1];
             for (int d = q.npts - 2; d >= 0; d--) acc = fe_add<F>(fe_mul<F>(acc, r), c[d]);
             running_claim = acc;
         }
         hs[q.chal_slot] = r;
-        mb_put(mb->chal, r);
     }
     // basic sumcheck, q.npts rounds from the 2^npts segment sums of the current table (basic_multi.cuh): the basic sumcheck on the
     // table of the sums, S -- round i sends its two half sums and folds its top variable by the challenge
@@ -320,17 +340,13 @@ template <class F> struct DeviceRounds {
                 }
                 if (!ok) { service_rc = ZK_E_HIP; break; }
             }
-            if (q.kind == kRound) serve_round(q);
-            else if (q.kind == kMulti) serve_multi(q);
-            else if (q.kind == kLink) serve_link(q);
-            else for (int k = 0; k < q.ntab; k++) hs[q.fin_slot + k] = mb_get(mb->fin + 12 * k);
-            if (q.kind == kRound) {                              // the answer line: limbs first, the two tags last (dev_transcript.cuh)
-                const Fe<F> &r = hs[q.chal_slot];
-                for (int i = 0; i < F::N; i++) __atomic_store_n(&mb->ans[1 + i], r.l[i], __ATOMIC_RELAXED);
-                __atomic_store_n(&mb->ans[0], (uint32_t)seq, __ATOMIC_RELEASE);
-                __atomic_store_n(&mb->ans[15], (uint32_t)seq, __ATOMIC_RELEASE);
+            if (q.kind == kRound) serve_round(q, seq);           // publishes its answer itself, as early as it can
+            else {
+                if (q.kind == kMulti) serve_multi(q);
+                else if (q.kind == kLink) serve_link(q);
+                else for (int k = 0; k < q.ntab; k++) hs[q.fin_slot + k] = mb_get(mb->fin + 12 * k);
+                __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
             }
-            __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
             served++;
         }
         // on failure, release every kernel that may still be waiting (they get a stale challenge; the call reports the error)
