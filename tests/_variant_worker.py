@@ -61,7 +61,27 @@ def main():
         if not (np.array_equal(result.round_univariate_polynomials, co) and np.array_equal(result.random_challenges, chal)
                 and t_gpu.sample_random_challenge() == t_cpu.sample_random_challenge()):
             bad.append(["gkr_sumcheck", field, nprod, nfac, logn])
-    print(json.dumps({"checked": checked, "mismatches": bad, "env": {k: v for k, v in os.environ.items() if k.startswith("ZK_")}}), flush=True)
+    # sparse GKR proof (zkmle_gkr_sparse.hip) of a layered circuit wide enough for the half-table gate weights (> 12 output bits): its digest
+    # must not depend on the code path (tests/test_gpu_variants.py compares the variants), and the sparse verifier must accept it
+    import hashlib
+    rng = np.random.default_rng(0xC1C)
+    lg, depth = 14, 2
+    n = 1 << lg
+    rows = []
+    for _ in range(depth):
+        g = np.zeros((n, 4), np.uint64)
+        g[:, 0] = rng.integers(0, n, n); g[:, 1] = rng.integers(0, n, n); g[:, 2] = rng.integers(0, n, n); g[:, 3] = rng.integers(0, 2, n)
+        rows.append(g)
+    x = rand_table(0, n, 4242)
+    proof = zk.gkr.sparse_prove(0, rows, [lg] * depth, x)
+    h = hashlib.sha256()
+    for arr in (proof.circuit_output, proof.claimed_sum, proof.layer_claims, proof.coeffs, proof.challenges, proof.wb_evals, proof.wc_evals,
+                proof.output_challenges):
+        h.update(np.ascontiguousarray(arr).tobytes())
+    checked += 1
+    if not zk.gkr.sparse_verify(0, rows, [lg] * depth, proof, x):
+        bad.append(["sparse_gkr_verify", lg, depth])
+    print(json.dumps({"checked": checked, "mismatches": bad, "sparse_gkr_digest": h.hexdigest(), "env": {k: v for k, v in os.environ.items() if k.startswith("ZK_")}}), flush=True)
 
 
 if __name__ == "__main__":

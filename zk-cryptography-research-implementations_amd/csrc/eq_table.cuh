@@ -86,18 +86,12 @@ template <class F> struct EqBuilder {
     // `scale` (may be null): the table times that constant, i.e. out[i] = scale * eq(point, i) -- the constant rides on the high
     // half table, so a weighted sum alpha eq(rb, .) + beta eq(rc, .) costs its consumers no products (zkmle_gkr_sparse.hip)
     // the same from a point that lives in device memory (element i at dev + i * stride elements; scale_dev: one element or null)
-    int build_dev(const void *dev, size_t stride, uint32_t nbits, void *out, const void *scale_dev = nullptr) {
+    // only the two half tables of a table of > kEqSmallBits variables (entry i of the full table = hi[i >> lbits] * lo[i & (2^lbits - 1)]):
+    // for consumers that gather a few entries each and can afford the product (zkmle_gkr_sparse.hip), 2 x 64 KB that stay in L2 instead of
+    // a 2^nbits-entry table written once and gathered from HBM.  The pointers stay valid until release().
+    int halves_dev(const void *dev, size_t stride, uint32_t nbits, const void **hi_out, const void **lo_out, unsigned *lbits_out,
+                   const void *scale_dev = nullptr) {
         const size_t esz = 4 * F::N;
-        if (nbits <= (uint32_t)kEqSmallBits) {
-            EqSmallArgs<F> a{};
-            a.nbits[0] = (int)nbits; a.nbits[1] = 0;
-            a.out[0] = out; a.out[1] = nullptr;
-            a.tau_dev[0] = dev; a.tau_dev[1] = nullptr; a.tau_stride = stride;
-            a.scaled[0] = scale_dev ? 1 : 0; a.scale_dev[0] = scale_dev;
-            eq_small_kernel<F><<<1, 1024, 0, cur_stream()>>>(a);
-            ZK_HIP(hipGetLastError());
-            return ZK_OK;
-        }
         const uint32_t hbits = nbits / 2, lbits = nbits - hbits;
         void *hi = nullptr, *lo = nullptr;
         ZK_TRY(pool_alloc(((size_t)1 << hbits) * esz, &hi));
@@ -117,24 +111,29 @@ template <class F> struct EqBuilder {
             ZK_TRY(build_dev(dev, stride, hbits, hi, scale_dev));
             ZK_TRY(build_dev(dev_lo, stride, lbits, lo));
         }
+        *hi_out = hi; *lo_out = lo; *lbits_out = lbits;
+        return ZK_OK;
+    }
+    int build_dev(const void *dev, size_t stride, uint32_t nbits, void *out, const void *scale_dev = nullptr) {
+        if (nbits <= (uint32_t)kEqSmallBits) {
+            EqSmallArgs<F> a{};
+            a.nbits[0] = (int)nbits; a.nbits[1] = 0;
+            a.out[0] = out; a.out[1] = nullptr;
+            a.tau_dev[0] = dev; a.tau_dev[1] = nullptr; a.tau_stride = stride;
+            a.scaled[0] = scale_dev ? 1 : 0; a.scale_dev[0] = scale_dev;
+            eq_small_kernel<F><<<1, 1024, 0, cur_stream()>>>(a);
+            ZK_HIP(hipGetLastError());
+            return ZK_OK;
+        }
+        const void *hi = nullptr, *lo = nullptr;
+        unsigned lbits = 0;
+        ZK_TRY(halves_dev(dev, stride, nbits, &hi, &lo, &lbits, scale_dev));
         const size_t n = (size_t)1 << nbits;
         eq_outer_kernel<F><<<grid_for(n), kBlock, 0, cur_stream()>>>(hi, lo, lbits, n, out);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
-    int build(const uint64_t *point, uint32_t nbits, void *out, const Fe<F> *scale = nullptr) {
-        if (nbits <= (uint32_t)kEqSmallBits) {
-            EqSmallArgs<F> a{};
-            load_taus(a.tau[0], point, nbits);
-            load_taus(a.tau[1], point, 0);
-            a.nbits[0] = (int)nbits; a.nbits[1] = 0;
-            a.out[0] = out; a.out[1] = nullptr;
-            a.scaled[0] = scale ? 1 : 0; a.scaled[1] = 0;
-            a.scale[0] = scale ? *scale : fe_zero<F>(); a.scale[1] = fe_zero<F>();
-            eq_small_kernel<F><<<1, 1024, 0, cur_stream()>>>(a);
-            ZK_HIP(hipGetLastError());
-            return ZK_OK;
-        }
+    int halves(const uint64_t *point, uint32_t nbits, const void **hi_out, const void **lo_out, unsigned *lbits_out, const Fe<F> *scale = nullptr) {
         const uint32_t hbits = nbits / 2, lbits = nbits - hbits;       // variables 0..hbits-1 are the high index bits
         void *hi = nullptr, *lo = nullptr;
         ZK_TRY(pool_alloc(((size_t)1 << hbits) * 4 * F::N, &hi));
@@ -155,6 +154,25 @@ template <class F> struct EqBuilder {
             ZK_TRY(build(point, hbits, hi, scale));
             ZK_TRY(build(point + (size_t)hbits * (F::N / 2), lbits, lo));
         }
+        *hi_out = hi; *lo_out = lo; *lbits_out = lbits;
+        return ZK_OK;
+    }
+    int build(const uint64_t *point, uint32_t nbits, void *out, const Fe<F> *scale = nullptr) {
+        if (nbits <= (uint32_t)kEqSmallBits) {
+            EqSmallArgs<F> a{};
+            load_taus(a.tau[0], point, nbits);
+            load_taus(a.tau[1], point, 0);
+            a.nbits[0] = (int)nbits; a.nbits[1] = 0;
+            a.out[0] = out; a.out[1] = nullptr;
+            a.scaled[0] = scale ? 1 : 0; a.scaled[1] = 0;
+            a.scale[0] = scale ? *scale : fe_zero<F>(); a.scale[1] = fe_zero<F>();
+            eq_small_kernel<F><<<1, 1024, 0, cur_stream()>>>(a);
+            ZK_HIP(hipGetLastError());
+            return ZK_OK;
+        }
+        const void *hi = nullptr, *lo = nullptr;
+        unsigned lbits = 0;
+        ZK_TRY(halves(point, nbits, &hi, &lo, &lbits, scale));
         const size_t n = (size_t)1 << nbits;
         eq_outer_kernel<F><<<grid_for(n), kBlock, 0, cur_stream()>>>(hi, lo, lbits, n, out);
         ZK_HIP(hipGetLastError());

@@ -58,40 +58,99 @@ template <class F> __global__ void gate_weights_kernel(const uint32_t *__restric
     if (eqB) v = fe_add<F>(v, fe_load<F>(eqB, out[i]));
     fe_store<F>(w, i, v);
 }
-// one lane per left index b.  The gates' right indices and operations are stored once more grouped by left index (start[b] ..
-// start[b + 1]) and read sequentially; the weight (gate order) and W[right] are the two gathers left.  (r1: with every field read
-// through the group's index list the kernel made four gathers per gate, 352 us for 2^22 gates; computing the weights directly in
-// the grouped orders was no better: it turns the sequential eq reads of an output-sorted gate list into two more gathers.)
-template <class F> __global__ void phase1_tables_kernel(const uint32_t *__restrict__ start, size_t nb, const void *__restrict__ w,
-                                                        const uint32_t *__restrict__ order, const uint32_t *__restrict__ right_l,
+// H1 / H0 (phase 1) and C / A (phase 2): for every index b of the grouping variable, two sums over the gates grouped under b (start[b] ..
+// start[b + 1], their other index and operation stored once more in grouped order and read sequentially; the weight (gate order) and
+// the table entry at the other index are the two gathers per gate).
+// Round 1 ran one lane per b over its own gates: a lane's gates are a serial chain of dependent gathers (~4 us each) and a wave lasts as long
+// as its longest lane -- 5-6 gates with random wiring, where the mean is 1: 300 us for 2^22 gates, latency x divergence, nowhere near the
+// ~150 us its traffic costs.  Now a workgroup owns 256 consecutive b, i.e. ONE contiguous range of the grouped gate list: one lane per GATE
+// does the gathers and the product (every lane exactly one chain link, all in flight together) and leaves the gate's two contributions in
+// LDS; then one lane per b adds up its run from LDS.  kPhaseChunk gates are staged per pass (256 + 64: a range of 256 b holds 256 +- 16
+// gates with random wiring, so one pass almost always); longer ranges (skewed circuits) take more passes.  Same sums, other order.
+constexpr int kPhaseChunk = kBlock + 64;
+// Where a gate's weight w_g = alpha eq(rb, out_g) + beta eq(rc, out_g) comes from.  Small layers: the table w (gate order), indexed through the
+// group's order list.  Layers of > kEqSmallBits output bits: straight from the HALF tables of the two eq tables (entry o = hi[o >> lbits] *
+// lo[o & mask], eq_table.cuh; the constants ride on the high halves), indexed by the gate's output index stored in grouped order -- four
+// 64 KB tables that live in L2 and two products per gate, instead of building two 2^out_bits tables, adding them up gate by gate into w
+// (three passes over 128 MB at 2^22) and gathering w from HBM.
+struct GateWeights {
+    const void *w;                       // non-null: the table of weights in gate order
+    const void *ah, *al, *bh, *bl;       // else: half tables of alpha eq(rb, .) and (bh non-null) beta eq(rc, .)
+    unsigned lbits;
+};
+template <class F> __device__ __forceinline__ Fe<F> gate_weight(const GateWeights &g, uint32_t idx) {
+    if (g.w) return fe_load<F>(g.w, idx);
+    const uint32_t h = idx >> g.lbits, l = idx & ((1u << g.lbits) - 1u);
+    Fe<F> v = fe_mul<F>(fe_load<F>(g.ah, h), fe_load<F>(g.al, l));
+    if (g.bh) v = fe_add<F>(v, fe_mul<F>(fe_load<F>(g.bh, h), fe_load<F>(g.bl, l)));
+    return v;
+}
+struct Phase1Op {            // per gate: w and t = w W[right]; add gate: H1 += w, H0 += t; mul gate: H1 += t
+    template <class F> static __device__ __forceinline__ void terms(const Fe<F> &wg, const Fe<F> &t, uint32_t op, Fe<F> &x, Fe<F> &y) {
+        if (op == 0) { x = wg; y = t; } else { x = t; y = fe_zero<F>(); }
+    }
+};
+struct Phase2Op {            // per gate: t = w eqL[left]; add gate: A += t; mul gate: M += t
+    template <class F> static __device__ __forceinline__ void terms(const Fe<F> &, const Fe<F> &t, uint32_t op, Fe<F> &x, Fe<F> &y) {
+        if (op == 0) { x = t; y = fe_zero<F>(); } else { x = fe_zero<F>(); y = t; }
+    }
+};
+template <class F, class Op>
+__device__ __forceinline__ void grouped_pair_sums(const uint32_t *__restrict__ start, size_t nb, const GateWeights &gw, const uint32_t *__restrict__ order,
+                                                  const uint32_t *__restrict__ other, const uint32_t *__restrict__ op, const void *__restrict__ tab,
+                                                  Fe<F> &sx, Fe<F> &sy) {
+    __shared__ Fe<F> cx[kPhaseChunk], cy[kPhaseChunk];
+    const unsigned tid = threadIdx.x;
+    const size_t b0 = (size_t)blockIdx.x * kBlock, b = b0 + tid;
+    const size_t nbk = nb - b0 < (size_t)kBlock ? nb - b0 : (size_t)kBlock;
+    const uint32_t e0 = start[b0], e1 = start[b0 + nbk];
+    const uint32_t rs = b < nb ? start[b] : e1, re = b < nb ? start[b + 1] : e1;      // this lane's run of the grouped list
+    sx = fe_zero<F>();
+    sy = fe_zero<F>();
+    for (uint32_t base = e0; base < e1; base += kPhaseChunk) {
+        // one lane per gate (the first 64 lanes take a second one): indices first, then both gathers, then the product
+        const uint32_t ea = base + tid, eb = base + kBlock + tid;
+        const bool va = ea < e1, vb = tid < (unsigned)(kPhaseChunk - kBlock) && eb < e1;
+        uint32_t oa = 0, ta = 0, pa = 0, ob = 0, tb = 0, pb = 0;
+        if (va) { oa = order[ea]; ta = other[ea]; pa = op[ea]; }
+        if (vb) { ob = order[eb]; tb = other[eb]; pb = op[eb]; }
+        Fe<F> wa, xa, wb, xb;
+        if (va) { xa = fe_load<F>(tab, ta); wa = gate_weight<F>(gw, oa); }
+        if (vb) { xb = fe_load<F>(tab, tb); wb = gate_weight<F>(gw, ob); }
+        if (va) Op::template terms<F>(wa, fe_mul<F>(wa, xa), pa, cx[tid], cy[tid]);
+        if (vb) Op::template terms<F>(wb, fe_mul<F>(wb, xb), pb, cx[kBlock + tid], cy[kBlock + tid]);
+        __syncthreads();
+        const uint32_t lo = rs > base ? rs : base, hi = re < base + kPhaseChunk ? re : base + (uint32_t)kPhaseChunk;
+        for (uint32_t e = lo; e < hi; e++) {
+            sx = fe_add<F>(sx, cx[e - base]);
+            sy = fe_add<F>(sy, cy[e - base]);
+        }
+        __syncthreads();
+    }
+}
+// `widx`: the group's order list (gw.w) or the gates' output indices in grouped order (half tables)
+template <class F> __global__ void __launch_bounds__(kBlock) phase1_tables_kernel(const uint32_t *__restrict__ start, size_t nb, GateWeights gw,
+                                                        const uint32_t *__restrict__ widx, const uint32_t *__restrict__ right_l,
                                                         const uint32_t *__restrict__ op_l,
                                                         const void *__restrict__ W, void *__restrict__ H1, void *__restrict__ H0) {
-    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fe<F> h1, h0;
+    grouped_pair_sums<F, Phase1Op>(start, nb, gw, widx, right_l, op_l, W, h1, h0);
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
-    Fe<F> h1 = fe_zero<F>(), h0 = fe_zero<F>();
-    for (uint32_t e = start[b]; e < start[b + 1]; e++) {
-        Fe<F> wg = fe_load<F>(w, order[e]);
-        Fe<F> t = fe_mul<F>(wg, fe_load<F>(W, right_l[e]));
-        if (op_l[e] == 0) { h1 = fe_add<F>(h1, wg); h0 = fe_add<F>(h0, t); }     // add gate
-        else h1 = fe_add<F>(h1, t);                                               // mul gate
-    }
     fe_store<F>(H1, b, h1);
     fe_store<F>(H0, b, h0);
 }
-// one lane per right index c (gates grouped by right index): A(c) = sum of the add gates' w eqL[left], M(c) the same over the mul gates;
+// gates grouped by right index c: A(c) = sum of the add gates' w eqL[left], M(c) the same over the mul gates;
 // stored: C = A + u M and A, so that phase 2 is the sumcheck of C(c) W(c) + u A(c)  (= A (u + W) + M u W)
-template <class F> __global__ void phase2_tables_kernel(const uint32_t *__restrict__ start, size_t nc, const void *__restrict__ w,
-                                                        const uint32_t *__restrict__ order, const uint32_t *__restrict__ left_r,
+template <class F> __global__ void __launch_bounds__(kBlock) phase2_tables_kernel(const uint32_t *__restrict__ start, size_t nc, GateWeights gw,
+                                                        const uint32_t *__restrict__ widx, const uint32_t *__restrict__ left_r,
                                                         const uint32_t *__restrict__ op_r,
                                                         const void *__restrict__ eqL, const void *__restrict__ u_dev, void *__restrict__ Cc, void *__restrict__ A) {
-    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fe<F> a, m;
+    grouped_pair_sums<F, Phase2Op>(start, nc, gw, widx, left_r, op_r, eqL, a, m);
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nc) return;
     const Fe<F> u = fe_load<F>(u_dev, 0);                      // W(rb*): a final value of phase 1, still on the device
-    Fe<F> a = fe_zero<F>(), m = fe_zero<F>();
-    for (uint32_t e = start[c]; e < start[c + 1]; e++) {
-        Fe<F> t = fe_mul<F>(fe_load<F>(w, order[e]), fe_load<F>(eqL, left_r[e]));
-        if (op_r[e] == 0) a = fe_add<F>(a, t); else m = fe_add<F>(m, t);
-    }
     fe_store<F>(Cc, c, fe_add<F>(a, fe_mul<F>(u, m)));
     fe_store<F>(A, c, a);
 }
@@ -128,6 +187,7 @@ struct LayerDev {
     DevBuf out, left, right, op;                       // u32[ngates]
     DevBuf ord_left, st_left, ord_right, st_right, ord_out, st_out;
     DevBuf l_right, l_op, r_left, r_op;                // right / op grouped by left index, left / op grouped by right index
+    DevBuf l_out, r_out;                               // output index in the two grouped orders (gate weights from half tables)
     GateArrays arrays() const { return GateArrays{(const uint32_t *)out.p, (const uint32_t *)left.p, (const uint32_t *)right.p, (const uint32_t *)op.p}; }
 };
 // counting sort of gate ids by key: order[], start[nbins + 1]
@@ -251,6 +311,10 @@ __global__ void permute2_kernel(const uint32_t *__restrict__ order, size_t n, co
     uint32_t i = order[e];
     oa[e] = a[i]; ob[e] = b[i];
 }
+__global__ void permute1_kernel(const uint32_t *__restrict__ order, size_t n, const uint32_t *__restrict__ a, uint32_t *__restrict__ oa) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) oa[e] = a[order[e]];
+}
 int group_by_device(const uint32_t *d_key, size_t n, size_t nbins, DevBuf &order, DevBuf &start) {
     DevBuf cursor;
     ZK_TRY(order.alloc((n ? n : 1) * 4));
@@ -284,12 +348,14 @@ int upload_layer(const zk_gate *g, size_t n, uint32_t out_bits, uint32_t in_bits
     ZK_TRY(group_by_device((const uint32_t *)L.left.p, n, (size_t)1 << in_bits, L.ord_left, L.st_left));
     ZK_TRY(group_by_device((const uint32_t *)L.right.p, n, (size_t)1 << in_bits, L.ord_right, L.st_right));
     ZK_TRY(group_by_device((const uint32_t *)L.out.p, n, (size_t)1 << out_bits, L.ord_out, L.st_out));
-    for (DevBuf *d : {&L.l_right, &L.l_op, &L.r_left, &L.r_op}) ZK_TRY(d->alloc((n ? n : 1) * 4));
+    for (DevBuf *d : {&L.l_right, &L.l_op, &L.r_left, &L.r_op, &L.l_out, &L.r_out}) ZK_TRY(d->alloc((n ? n : 1) * 4));
     if (n) {
         permute2_kernel<<<blocks(n), kBlock, 0, cur_stream()>>>((const uint32_t *)L.ord_left.p, n, (const uint32_t *)L.right.p, (const uint32_t *)L.op.p,
                                                                (uint32_t *)L.l_right.p, (uint32_t *)L.l_op.p);
         permute2_kernel<<<blocks(n), kBlock, 0, cur_stream()>>>((const uint32_t *)L.ord_right.p, n, (const uint32_t *)L.left.p, (const uint32_t *)L.op.p,
                                                                (uint32_t *)L.r_left.p, (uint32_t *)L.r_op.p);
+        permute1_kernel<<<blocks(n), kBlock, 0, cur_stream()>>>((const uint32_t *)L.ord_left.p, n, (const uint32_t *)L.out.p, (uint32_t *)L.l_out.p);
+        permute1_kernel<<<blocks(n), kBlock, 0, cur_stream()>>>((const uint32_t *)L.ord_right.p, n, (const uint32_t *)L.out.p, (uint32_t *)L.r_out.p);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipStreamSynchronize(cur_stream()));
     }
@@ -389,22 +455,38 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         // alpha / beta are read from its slots, the constants folded into the eq half tables (eq_table.cuh)
         TablePtr eqA, eqB;
         DevBuf w;
-        ZK_TRY(w.alloc((ng ? ng : 1) * esz));
-        if (l == 0) {
-            ZK_TRY((eq_table<F>(ra.data(), Ly.out_bits, eqA)));
-            if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, nullptr, w.p);
+        EqBuilder<F> ebA, ebB;                                 // the half tables live until the layer's kernels are enqueued (stream-ordered pool)
+        GateWeights gw{};
+        static const bool want_table = [] { const char *e = getenv("ZK_GKR_WEIGHT_TABLE"); return e && e[0] == '1'; }();   // measurements / tests
+        const bool halves = Ly.out_bits > (uint32_t)kEqSmallBits && ng > 0 && !want_table;
+        if (halves) {
+            if (l == 0) {
+                ZK_TRY(ebA.halves(ra.data(), Ly.out_bits, &gw.ah, &gw.al, &gw.lbits));
+            } else {
+                const size_t p1 = base[l - 1], p2 = p1 + per * layers[l - 1].in_bits + 4, plk = p2 + per * layers[l - 1].in_bits + 4;
+                unsigned lb2 = 0;
+                ZK_TRY(ebA.halves_dev(ps->slot_ptr(p1 + 3), per, Ly.out_bits, &gw.ah, &gw.al, &gw.lbits, ps->slot_ptr(plk + 2)));   // alpha eq(rb, .)
+                ZK_TRY(ebB.halves_dev(ps->slot_ptr(p2 + 3), per, Ly.out_bits, &gw.bh, &gw.bl, &lb2, ps->slot_ptr(plk + 3)));        // beta eq(rc, .)
+            }
         } else {
-            const size_t p1 = base[l - 1], p2 = p1 + per * layers[l - 1].in_bits + 4, plk = p2 + per * layers[l - 1].in_bits + 4;
-            ZK_TRY((eq_table_dev<F>(ps->slot_ptr(p1 + 3), per, Ly.out_bits, eqA, ps->slot_ptr(plk + 2))));     // alpha eq(rb, .)
-            ZK_TRY((eq_table_dev<F>(ps->slot_ptr(p2 + 3), per, Ly.out_bits, eqB, ps->slot_ptr(plk + 3))));     // beta eq(rc, .)
-            if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, eqB->dptr, w.p);
+            ZK_TRY(w.alloc((ng ? ng : 1) * esz));
+            if (l == 0) {
+                ZK_TRY((eq_table<F>(ra.data(), Ly.out_bits, eqA)));
+                if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, nullptr, w.p);
+            } else {
+                const size_t p1 = base[l - 1], p2 = p1 + per * layers[l - 1].in_bits + 4, plk = p2 + per * layers[l - 1].in_bits + 4;
+                ZK_TRY((eq_table_dev<F>(ps->slot_ptr(p1 + 3), per, Ly.out_bits, eqA, ps->slot_ptr(plk + 2))));     // alpha eq(rb, .)
+                ZK_TRY((eq_table_dev<F>(ps->slot_ptr(p2 + 3), per, Ly.out_bits, eqB, ps->slot_ptr(plk + 3))));     // beta eq(rc, .)
+                if (ng) gate_weights_kernel<F><<<blocks(ng), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.out.p, ng, eqA->dptr, eqB->dptr, w.p);
+            }
+            gw.w = w.p;
         }
         ZK_HIP(hipGetLastError());
         // phase 1 (rounds over b): f = W(b) H1(b) + H0(b) * 1 -- the second product's factor is the constant one, never a table
         TablePtr H1, H0;
         ZK_TRY(alloc_table(F::ID, nk, H1));
         ZK_TRY(alloc_table(F::ID, nk, H0));
-        phase1_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_left.p, nk, w.p, (const uint32_t *)Ly.ord_left.p,
+        phase1_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_left.p, nk, gw, (const uint32_t *)(halves ? Ly.l_out.p : Ly.ord_left.p),
                                                          (const uint32_t *)Ly.l_right.p, (const uint32_t *)Ly.l_op.p, Wn->dptr, H1->dptr, H0->dptr);
         ZK_HIP(hipGetLastError());
         const zk_table *t1[4] = {Wn, H1.get(), H0.get(), nullptr};
@@ -417,7 +499,7 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         ZK_TRY((eq_table_dev<F>(ps->slot_ptr(s1 + 3), per, k, eqL)));
         ZK_TRY(alloc_table(F::ID, nk, Cc));
         ZK_TRY(alloc_table(F::ID, nk, A));
-        phase2_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_right.p, nk, w.p, (const uint32_t *)Ly.ord_right.p,
+        phase2_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_right.p, nk, gw, (const uint32_t *)(halves ? Ly.r_out.p : Ly.ord_right.p),
                                                          (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, eqL->dptr, u_dev, Cc->dptr, A->dptr);
         ZK_HIP(hipGetLastError());
         const zk_table *t2[4] = {Cc.get(), Wn, A.get(), nullptr};
