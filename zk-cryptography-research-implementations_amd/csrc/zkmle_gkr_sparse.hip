@@ -63,11 +63,12 @@ template <class F> __global__ void gate_weights_kernel(const uint32_t *__restric
 // the table entry at the other index are the two gathers per gate).
 // Round 1 ran one lane per b over its own gates: a lane's gates are a serial chain of dependent gathers (~4 us each) and a wave lasts as long
 // as its longest lane -- 5-6 gates with random wiring, where the mean is 1: 300 us for 2^22 gates, latency x divergence, nowhere near the
-// ~150 us its traffic costs.  Now a workgroup owns 256 consecutive b, i.e. ONE contiguous range of the grouped gate list: one lane per GATE
+// ~150 us its traffic costs.  Now a workgroup owns a range of consecutive b, i.e. ONE contiguous range of the grouped gate list: one lane per GATE
 // does the gathers and the product (every lane exactly one chain link, all in flight together) and leaves the gate's two contributions in
-// LDS; then one lane per b adds up its run from LDS.  kPhaseChunk gates are staged per pass (256 + 64: a range of 256 b holds 256 +- 16
-// gates with random wiring, so one pass almost always); longer ranges (skewed circuits) take more passes.  Same sums, other order.
-constexpr int kPhaseChunk = kBlock + 64;
+// LDS; then one lane per b adds up its run from LDS.  A workgroup of 256 lanes owns kPhaseGroups = 224 consecutive b: with one gate per b
+// on average (random wiring: 224 +- 15 gates) their gates fit ONE pass of 256 gate lanes 98 % of the time; longer ranges (skewed circuits)
+// take more passes of 256.  Same sums, other order.
+constexpr int kPhaseGroups = kBlock - 32;
 // Where a gate's weight w_g = alpha eq(rb, out_g) + beta eq(rc, out_g) comes from.  Small layers: the table w (gate order), indexed through the
 // group's order list.  Layers of > kEqSmallBits output bits: straight from the HALF tables of the two eq tables (entry o = hi[o >> lbits] *
 // lo[o & mask], eq_table.cuh; the constants ride on the high halves), indexed by the gate's output index stored in grouped order -- four
@@ -99,31 +100,28 @@ template <class F, class Op>
 __device__ __forceinline__ void grouped_pair_sums(const uint32_t *__restrict__ start, size_t nb, const GateWeights &gw, const uint32_t *__restrict__ order,
                                                   const uint32_t *__restrict__ other, const uint32_t *__restrict__ op, const void *__restrict__ tab,
                                                   Fe<F> &sx, Fe<F> &sy) {
-    __shared__ Fe<F> cx[kPhaseChunk], cy[kPhaseChunk];
+    __shared__ Fe<F> cx[kBlock], cy[kBlock];
     const unsigned tid = threadIdx.x;
-    const size_t b0 = (size_t)blockIdx.x * kBlock, b = b0 + tid;
-    const size_t nbk = nb - b0 < (size_t)kBlock ? nb - b0 : (size_t)kBlock;
+    const size_t b0 = (size_t)blockIdx.x * kPhaseGroups, b = b0 + tid;
+    const size_t nbk = nb - b0 < (size_t)kPhaseGroups ? nb - b0 : (size_t)kPhaseGroups;
+    const bool mine = tid < nbk;                                                        // this lane owns index b
     const uint32_t e0 = start[b0], e1 = start[b0 + nbk];
-    const uint32_t rs = b < nb ? start[b] : e1, re = b < nb ? start[b + 1] : e1;      // this lane's run of the grouped list
+    const uint32_t rs = mine ? start[b] : e1, re = mine ? start[b + 1] : e1;             // its run of the grouped list
     sx = fe_zero<F>();
     sy = fe_zero<F>();
-    for (uint32_t base = e0; base < e1; base += kPhaseChunk) {
-        // one lane per gate (the first 64 lanes take a second one): indices first, then both gathers, then the product
-        const uint32_t ea = base + tid, eb = base + kBlock + tid;
-        const bool va = ea < e1, vb = tid < (unsigned)(kPhaseChunk - kBlock) && eb < e1;
-        uint32_t oa = 0, ta = 0, pa = 0, ob = 0, tb = 0, pb = 0;
-        if (va) { oa = order[ea]; ta = other[ea]; pa = op[ea]; }
-        if (vb) { ob = order[eb]; tb = other[eb]; pb = op[eb]; }
-        Fe<F> wa, xa, wb, xb;
-        if (va) { xa = fe_load<F>(tab, ta); wa = gate_weight<F>(gw, oa); }
-        if (vb) { xb = fe_load<F>(tab, tb); wb = gate_weight<F>(gw, ob); }
-        if (va) Op::template terms<F>(wa, fe_mul<F>(wa, xa), pa, cx[tid], cy[tid]);
-        if (vb) Op::template terms<F>(wb, fe_mul<F>(wb, xb), pb, cx[kBlock + tid], cy[kBlock + tid]);
+    for (uint32_t base = e0; base < e1; base += kBlock) {
+        const uint32_t e = base + tid;                                                  // one lane per gate
+        if (e < e1) {
+            const uint32_t oi = order[e], ti = other[e], pi = op[e];
+            const Fe<F> x = fe_load<F>(tab, ti);
+            const Fe<F> wg = gate_weight<F>(gw, oi);
+            Op::template terms<F>(wg, fe_mul<F>(wg, x), pi, cx[tid], cy[tid]);
+        }
         __syncthreads();
-        const uint32_t lo = rs > base ? rs : base, hi = re < base + kPhaseChunk ? re : base + (uint32_t)kPhaseChunk;
-        for (uint32_t e = lo; e < hi; e++) {
-            sx = fe_add<F>(sx, cx[e - base]);
-            sy = fe_add<F>(sy, cy[e - base]);
+        const uint32_t lo = rs > base ? rs : base, hi = re < base + kBlock ? re : base + (uint32_t)kBlock;
+        for (uint32_t k = lo; k < hi; k++) {
+            sx = fe_add<F>(sx, cx[k - base]);
+            sy = fe_add<F>(sy, cy[k - base]);
         }
         __syncthreads();
     }
@@ -135,8 +133,8 @@ template <class F> __global__ void __launch_bounds__(kBlock) phase1_tables_kerne
                                                         const void *__restrict__ W, void *__restrict__ H1, void *__restrict__ H0) {
     Fe<F> h1, h0;
     grouped_pair_sums<F, Phase1Op>(start, nb, gw, widx, right_l, op_l, W, h1, h0);
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+    const size_t b = (size_t)blockIdx.x * kPhaseGroups + threadIdx.x;
+    if (threadIdx.x >= (unsigned)kPhaseGroups || b >= nb) return;
     fe_store<F>(H1, b, h1);
     fe_store<F>(H0, b, h0);
 }
@@ -148,8 +146,8 @@ template <class F> __global__ void __launch_bounds__(kBlock) phase2_tables_kerne
                                                         const void *__restrict__ eqL, const void *__restrict__ u_dev, void *__restrict__ Cc, void *__restrict__ A) {
     Fe<F> a, m;
     grouped_pair_sums<F, Phase2Op>(start, nc, gw, widx, left_r, op_r, eqL, a, m);
-    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nc) return;
+    const size_t c = (size_t)blockIdx.x * kPhaseGroups + threadIdx.x;
+    if (threadIdx.x >= (unsigned)kPhaseGroups || c >= nc) return;
     const Fe<F> u = fe_load<F>(u_dev, 0);                      // W(rb*): a final value of phase 1, still on the device
     fe_store<F>(Cc, c, fe_add<F>(a, fe_mul<F>(u, m)));
     fe_store<F>(A, c, a);
@@ -486,7 +484,7 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         TablePtr H1, H0;
         ZK_TRY(alloc_table(F::ID, nk, H1));
         ZK_TRY(alloc_table(F::ID, nk, H0));
-        phase1_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_left.p, nk, gw, (const uint32_t *)(halves ? Ly.l_out.p : Ly.ord_left.p),
+        phase1_tables_kernel<F><<<(unsigned)((nk + kPhaseGroups - 1) / kPhaseGroups), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_left.p, nk, gw, (const uint32_t *)(halves ? Ly.l_out.p : Ly.ord_left.p),
                                                          (const uint32_t *)Ly.l_right.p, (const uint32_t *)Ly.l_op.p, Wn->dptr, H1->dptr, H0->dptr);
         ZK_HIP(hipGetLastError());
         const zk_table *t1[4] = {Wn, H1.get(), H0.get(), nullptr};
@@ -499,7 +497,7 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         ZK_TRY((eq_table_dev<F>(ps->slot_ptr(s1 + 3), per, k, eqL)));
         ZK_TRY(alloc_table(F::ID, nk, Cc));
         ZK_TRY(alloc_table(F::ID, nk, A));
-        phase2_tables_kernel<F><<<blocks(nk), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_right.p, nk, gw, (const uint32_t *)(halves ? Ly.r_out.p : Ly.ord_right.p),
+        phase2_tables_kernel<F><<<(unsigned)((nk + kPhaseGroups - 1) / kPhaseGroups), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_right.p, nk, gw, (const uint32_t *)(halves ? Ly.r_out.p : Ly.ord_right.p),
                                                          (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, eqL->dptr, u_dev, Cc->dptr, A->dptr);
         ZK_HIP(hipGetLastError());
         const zk_table *t2[4] = {Cc.get(), Wn, A.get(), nullptr};
