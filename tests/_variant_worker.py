@@ -65,7 +65,7 @@ def main():
     # must not depend on the code path (tests/test_gpu_variants.py compares the variants), and the sparse verifier must accept it
     import hashlib
     rng = np.random.default_rng(0xC1C)
-    lg, depth = 14, 2
+    lg, depth = 15, 2                    # half a table = 2^14 entries: round 0 derives e(1) from the claim in the host-assisted mode only
     n = 1 << lg
     rows = []
     for _ in range(depth):

@@ -28,6 +28,6 @@ def test_variant_reproduces_oracle_proofs(env):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["checked"] >= 20
     assert out["mismatches"] == [], out
-    # the sparse GKR proof of a 2^14-wide circuit: the same bytes whichever way the gate weights and the transcript step are computed
+    # the sparse GKR proof of a 2^15-wide circuit: the same bytes whichever way the gate weights and the transcript step are computed
     DIGESTS[tuple(sorted(env.items()))] = out["sparse_gkr_digest"]
     assert out["sparse_gkr_digest"] == DIGESTS[()], (env, DIGESTS)

@@ -81,6 +81,9 @@ struct ProofSlotsBase {
     virtual int rounds(size_t s0, const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *const_host, const void *const *const_dev,
                        int with_claim, size_t claim_slot) = 0;
     // gkr_protocol.rs:109-133 on the device: append wb, alpha, append wc, beta, claim = alpha wb + beta wc
+    // every sumcheck enqueued through rounds() proves a sum the prover computed itself; the first one's is told here (the later ones' are the
+    // running claim of the previous phase or link), so that round 0 may derive e(1) = claim - e(0)
+    virtual void set_claim(const uint64_t *el) = 0;
     virtual int link(size_t wb_src, size_t wc_src, size_t wb_slot, size_t wc_slot, size_t alpha_slot, size_t beta_slot, size_t claim_slot) = 0;
     virtual int collect(Transcript &tr, uint64_t *host_slots) = 0;   // every slot (field elements, u64 limbs) + the sponge back into tr
 };

@@ -224,7 +224,7 @@ __device__ __forceinline__ void write_partials(Wide<F> (&acc)[NFAC + 1], Wide<F>
 
 // tables of `2 * half` entries; partials[t * gridDim.x + block]
 template <class F, int NFAC>
-__global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials) {
+__global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials, int skip1 = 0) {
     if constexpr (NFAC == 2 && LazyProducts<F>::value) {
         __shared__ ProdWide<F> shp[3 * kBlock / 64];
         ProdAcc<F> pacc[3] = {prod_zero<F>(), prod_zero<F>(), prod_zero<F>()};
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
                     lo[f] = fe_load<F>(tabs.in[p * 2 + f], i);
                     hi[f] = fe_load<F>(tabs.in[p * 2 + f], i + half);
                 }
-                accumulate_terms_lazy<F>(lo, hi, pacc, 0);
+                accumulate_terms_lazy<F>(lo, hi, pacc, skip1);
                 if (++pending == kProdCarryEvery) {
                     pending = 0;
 #pragma unroll
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
                 }
             }
         }
-        write_partials_lazy<F>(pacc, shp, partials, 0);
+        write_partials_lazy<F>(pacc, shp, partials, skip1);
         return;
     }
     __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];

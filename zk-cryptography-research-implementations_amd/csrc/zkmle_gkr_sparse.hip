@@ -437,6 +437,7 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
     ProofSlotsBase *psp = nullptr;
     ZK_TRY(proof_slots_new(F::ID, tr.t, 3, base[nlayers], &psp));
     std::unique_ptr<ProofSlotsBase> ps(psp);
+    ps->set_claim(claim0);                                                           // layer 0's claimed sum, computed above
     std::vector<hipEvent_t> ev(ms_layers ? 2 * nlayers : 0);
     for (hipEvent_t &e : ev) ZK_HIP(hipEventCreate(&e));
     struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (hipEvent_t e : v) (void)hipEventDestroy(e); } } ev_guard{ev};

@@ -699,10 +699,11 @@ int check_sumpoly_cf(const zk_table *const *tables, size_t nprod, size_t nfac, c
     return ZK_OK;
 }
 
-template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t half, void *part, int grid) {
-    if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
-    else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
-    else round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
+// skip1: the two-factor lazy kernel leaves out the products of the point 1 (the caller derives e(1) = claim - e(0)); others ignore it
+template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t half, void *part, int grid, int skip1 = 0) {
+    if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, 0);
+    else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, skip1);
+    else round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, 0);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -769,8 +770,12 @@ template <class F> const std::vector<Fe<F>> &sumcheck_basis(size_t npts) {
 // coefficients at s0 + per k, its challenge at s0 + per k + npts, the ntab final values at s0 + per nvars (per = npts + 1).
 // Constant second factors: tables[p * 2 + 1] == null, value from const_host (nprod elements) or const_dev[p] (device memory).
 // with_claim: proof[claim_slot] (already on the device) is absorbed big-endian in front of round 0's message (:35).
+// own_claim: the claimed sum of this sumcheck was computed by the prover itself (a layer of a GKR proof: the previous phase's / link's
+// running claim), so round 0 may take e(1) = claim - e(0) like every later round does; a claim that comes from outside (zk_sumcheck_gkr_prove)
+// may be wrong, and the reference then sends the true e(1).
 template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const zk_table *const *tables, size_t nprod, size_t nfac,
-                                          const uint64_t *const_host, const void *const *const_dev, int with_claim, size_t claim_slot) {
+                                          const uint64_t *const_host, const void *const *const_dev, int with_claim, size_t claim_slot,
+                                          bool own_claim = false) {
     const size_t esz = 4 * F::N, L64 = F::N / 2;
     const size_t ntab = nprod * nfac, npts = nfac + 1;                 // degree() = polynomials.len() (:114, sum_polynomial.rs:88)
     size_t len = tables[0]->len;
@@ -793,8 +798,10 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
     {   // round 0 evaluations
         size_t half = len / 2;
         int grid = reduce_grid_for(half);
-        ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
-        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, with_claim, claim_slot, s0, s0 + npts));
+        // host-assisted step only: the host keeps the running claim (the device variant reads the previous round's slots, which round 0 has not)
+        const int skip0 = (own_claim && dr.host_mode && nfac == 2 && LazyProducts<F>::value && half >= ((size_t)1 << 14)) ? 1 : 0;
+        ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid, skip0)));
+        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, with_claim, claim_slot, s0, s0 + npts, skip0, per));
     }
     char *dst = (char *)bufA.p, *other = (char *)bufB.p;
     size_t cl = len;
@@ -1086,7 +1093,12 @@ template <class F> struct ProofSlotsImpl : ProofSlotsBase {
     }
     int rounds(size_t s0, const zk_table *const *tables, size_t nprod, size_t nfac, const uint64_t *const_host, const void *const *const_dev,
                int with_claim, size_t claim_slot) override {
-        return gkr_rounds_enqueue<F>(dr, s0, tables, nprod, nfac, const_host, const_dev, with_claim, claim_slot);
+        return gkr_rounds_enqueue<F>(dr, s0, tables, nprod, nfac, const_host, const_dev, with_claim, claim_slot, true);
+    }
+    void set_claim(const uint64_t *el) override {                      // the claimed sum of the first sumcheck (later ones: running claim / link)
+        Fe<F> e;
+        memcpy(e.l, el, 4 * F::N);
+        dr.running_claim = e;
     }
     int link(size_t wb_src, size_t wc_src, size_t wb_slot, size_t wc_slot, size_t alpha_slot, size_t beta_slot, size_t claim_slot) override {
         if (dr.host_mode) return dr.launch_link_host(wb_src, wc_src, wb_slot, wc_slot, alpha_slot, beta_slot, claim_slot);
