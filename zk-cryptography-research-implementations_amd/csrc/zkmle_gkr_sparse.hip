@@ -79,6 +79,16 @@ struct GateWeights {
     const void *ah, *al, *bh, *bl;       // else: half tables of alpha eq(rb, .) and (bh non-null) beta eq(rc, .)
     unsigned lbits;
 };
+// the table gathered at a gate's other index: an array (W in phase 1), or the half tables of an eq table (eq(rb*, .) in phase 2)
+struct OtherTable {
+    const void *tab;                     // non-null: the table itself
+    const void *hi, *lo;                 // else its half tables
+    unsigned lbits;
+};
+template <class F> __device__ __forceinline__ Fe<F> other_entry(const OtherTable &t, uint32_t idx) {
+    if (t.tab) return fe_load<F>(t.tab, idx);
+    return fe_mul<F>(fe_load<F>(t.hi, idx >> t.lbits), fe_load<F>(t.lo, idx & ((1u << t.lbits) - 1u)));
+}
 template <class F> __device__ __forceinline__ Fe<F> gate_weight(const GateWeights &g, uint32_t idx) {
     if (g.w) return fe_load<F>(g.w, idx);
     const uint32_t h = idx >> g.lbits, l = idx & ((1u << g.lbits) - 1u);
@@ -98,7 +108,7 @@ struct Phase2Op {            // per gate: t = w eqL[left]; add gate: A += t; mul
 };
 template <class F, class Op>
 __device__ __forceinline__ void grouped_pair_sums(const uint32_t *__restrict__ start, size_t nb, const GateWeights &gw, const uint32_t *__restrict__ order,
-                                                  const uint32_t *__restrict__ other, const uint32_t *__restrict__ op, const void *__restrict__ tab,
+                                                  const uint32_t *__restrict__ other, const uint32_t *__restrict__ op, const OtherTable &tab,
                                                   Fe<F> &sx, Fe<F> &sy) {
     __shared__ Fe<F> cx[kBlock], cy[kBlock];
     const unsigned tid = threadIdx.x;
@@ -113,7 +123,7 @@ __device__ __forceinline__ void grouped_pair_sums(const uint32_t *__restrict__ s
         const uint32_t e = base + tid;                                                  // one lane per gate
         if (e < e1) {
             const uint32_t oi = order[e], ti = other[e], pi = op[e];
-            const Fe<F> x = fe_load<F>(tab, ti);
+            const Fe<F> x = other_entry<F>(tab, ti);
             const Fe<F> wg = gate_weight<F>(gw, oi);
             Op::template terms<F>(wg, fe_mul<F>(wg, x), pi, cx[tid], cy[tid]);
         }
@@ -132,7 +142,7 @@ template <class F> __global__ void __launch_bounds__(kBlock) phase1_tables_kerne
                                                         const uint32_t *__restrict__ op_l,
                                                         const void *__restrict__ W, void *__restrict__ H1, void *__restrict__ H0) {
     Fe<F> h1, h0;
-    grouped_pair_sums<F, Phase1Op>(start, nb, gw, widx, right_l, op_l, W, h1, h0);
+    grouped_pair_sums<F, Phase1Op>(start, nb, gw, widx, right_l, op_l, OtherTable{W, nullptr, nullptr, 0}, h1, h0);
     const size_t b = (size_t)blockIdx.x * kPhaseGroups + threadIdx.x;
     if (threadIdx.x >= (unsigned)kPhaseGroups || b >= nb) return;
     fe_store<F>(H1, b, h1);
@@ -143,7 +153,7 @@ template <class F> __global__ void __launch_bounds__(kBlock) phase1_tables_kerne
 template <class F> __global__ void __launch_bounds__(kBlock) phase2_tables_kernel(const uint32_t *__restrict__ start, size_t nc, GateWeights gw,
                                                         const uint32_t *__restrict__ widx, const uint32_t *__restrict__ left_r,
                                                         const uint32_t *__restrict__ op_r,
-                                                        const void *__restrict__ eqL, const void *__restrict__ u_dev, void *__restrict__ Cc, void *__restrict__ A) {
+                                                        OtherTable eqL, const void *__restrict__ u_dev, void *__restrict__ Cc, void *__restrict__ A) {
     Fe<F> a, m;
     grouped_pair_sums<F, Phase2Op>(start, nc, gw, widx, left_r, op_r, eqL, a, m);
     const size_t c = (size_t)blockIdx.x * kPhaseGroups + threadIdx.x;
@@ -495,11 +505,18 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         // A(c) (u + W(c)) + M(c) u W(c) = C(c) W(c) + A(c) * u with C = A + u M
         const void *u_dev = ps->slot_ptr(s1 + per * k);
         TablePtr eqL, Cc, A;
-        ZK_TRY((eq_table_dev<F>(ps->slot_ptr(s1 + 3), per, k, eqL)));
+        EqBuilder<F> ebL;
+        OtherTable tl{};
+        if (k > (uint32_t)kEqSmallBits && !want_table) {           // eq(rb*, .) is only gathered once per gate: half tables do (as for the weights)
+            ZK_TRY(ebL.halves_dev(ps->slot_ptr(s1 + 3), per, k, &tl.hi, &tl.lo, &tl.lbits));
+        } else {
+            ZK_TRY((eq_table_dev<F>(ps->slot_ptr(s1 + 3), per, k, eqL)));
+            tl.tab = eqL->dptr;
+        }
         ZK_TRY(alloc_table(F::ID, nk, Cc));
         ZK_TRY(alloc_table(F::ID, nk, A));
         phase2_tables_kernel<F><<<(unsigned)((nk + kPhaseGroups - 1) / kPhaseGroups), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_right.p, nk, gw, (const uint32_t *)(halves ? Ly.r_out.p : Ly.ord_right.p),
-                                                         (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, eqL->dptr, u_dev, Cc->dptr, A->dptr);
+                                                         (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, tl, u_dev, Cc->dptr, A->dptr);
         ZK_HIP(hipGetLastError());
         const zk_table *t2[4] = {Cc.get(), Wn, A.get(), nullptr};
         const void *cdev[2] = {nullptr, u_dev};
