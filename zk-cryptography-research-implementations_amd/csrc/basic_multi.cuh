@@ -73,8 +73,8 @@ template <class F> __global__ void __launch_bounds__(64 << kMultiMax) multi_fini
     __syncthreads();
     if (wave != 0) return;
     mailbox_post<F>(a.mb, a.mb->fin, ev, 1 << a.m, a.seq, lane);
-    mailbox_wait(a.mb, a.seq, lane);
-    if ((int)lane < a.m) fe_store<F>(a.proof, a.chal_slot + a.per * lane, mailbox_element<F>(lane == 0 ? a.mb->chal : a.mb->aux[lane - 1]));
+    const Fe<F> r = mailbox_wait_challenges<F>(a.mb, a.seq, lane, (unsigned)a.m);
+    if ((int)lane < a.m) fe_store<F>(a.proof, a.chal_slot + a.per * lane, r);
 }
 
 // Every round of a table of <= kTailLen entries (none of them started), one workgroup: per exchange up to kMultiMax rounds -- segment sums,
@@ -114,9 +114,8 @@ template <class F> __global__ void __launch_bounds__(kTailBlock) basic_tail_kern
         if (wave == 0) {
             mailbox_post<F>(a.mb, a.mb->fin, ev, (int)nseg, seq, lane);
             if (seglen > 1) {
-                mailbox_wait(a.mb, seq, lane);
+                const Fe<F> r = mailbox_wait_challenges<F>(a.mb, seq, lane, m);
                 if (lane < m) {
-                    const Fe<F> r = mailbox_element<F>(lane == 0 ? a.mb->chal : a.mb->aux[lane - 1]);
                     ch[lane] = r;
                     fe_store<F>(a.proof, cs + a.per * lane, r);
                 }

@@ -169,8 +169,11 @@ struct HostMailbox {
     // per round): dword 0 and dword 15 = the request number (low 32 bits), dwords 1 .. 12 = the challenge's limbs.  The host writes the
     // limbs first and the two tags last; a tag in each 32-byte half keeps the test sound even if the line were fetched as two halves.
     uint32_t ans[16];
+    uint32_t ans4[4][16];               // the same for an exchange that answers with up to four challenges (basic_multi.cuh): one line each
 };
 static_assert(offsetof(HostMailbox, ans) % 64 == 0, "the answer line must not straddle two lines");
+static_assert(offsetof(HostMailbox, ans4) % 64 == 0, "the answer lines must not straddle lines");
+static_assert(sizeof(HostMailbox) <= 4096, "the mailbox is one pinned page (zkmle_core.hip host_mailbox)");
 constexpr long long kMailboxSpinBudget = 2000000;       // polls of ~0.7-1.5 us each: 1.5-3 s
 
 // wave 0, uniform: post `nel` elements from `src` (LDS) as request `seq`
@@ -215,6 +218,32 @@ template <class F> __device__ __forceinline__ Fe<F> mailbox_wait_challenge(HostM
     Fe<F> e;
 #pragma unroll
     for (int i = 0; i < F::N; i++) e.l[i] = __builtin_amdgcn_readlane(v, 1 + i);
+    return e;
+}
+// wave 0, uniform: the same for an exchange of m <= 4 challenges, one answer line each (all four lines are read by one load of the wave):
+// lane i < m returns challenge i
+template <class F> __device__ __forceinline__ Fe<F> mailbox_wait_challenges(HostMailbox *mb, uint64_t seq, unsigned lane, unsigned m) {
+    const uint32_t tag = (uint32_t)seq;
+    uint32_t v = 0;
+    long long spins = 0;
+    for (;;) {
+        v = __hip_atomic_load(&mb->ans4[0][0] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        bool ok = true;
+        for (unsigned i = 0; i < m; i++) ok = ok && __builtin_amdgcn_readlane(v, 16 * i) == tag && __builtin_amdgcn_readlane(v, 16 * i + 15) == tag;
+        if (ok) break;
+        int stop = 0;
+        if (lane == 0 && ((++spins & 63) == 0)) {
+            if (spins > kMailboxSpinBudget || __atomic_load_n(&mb->aborted, __ATOMIC_RELAXED) != 0 ||
+                __atomic_load_n(&mb->cpu_seq, __ATOMIC_ACQUIRE) > seq + ((uint64_t)1 << 40)) { mb->aborted = seq; stop = 1; }
+        }
+        if (__builtin_amdgcn_readfirstlane(stop)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    Fe<F> e;
+    const unsigned line = lane < m ? lane : 0u;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) e.l[i] = (uint32_t)__shfl((int)v, (int)(16 * line + 1 + i));
     return e;
 }
 template <class F> __device__ __forceinline__ Fe<F> mailbox_element(const uint32_t *src) {

@@ -274,7 +274,7 @@ template <class F> struct DeviceRounds {
     }
     // basic sumcheck, q.npts rounds from the 2^npts segment sums of the current table (basic_multi.cuh): the basic sumcheck on the
     // table of the sums, S -- round i sends its two half sums and folds its top variable by the challenge
-    void serve_multi(const Req &q) {
+    void serve_multi(const Req &q, uint64_t seq) {
         const int m = q.npts;
         const size_t per = q.s[0];
         size_t n = (size_t)1 << m;
@@ -294,9 +294,13 @@ template <class F> struct DeviceRounds {
             const Fe<F> r = htr->template random_challenge_as_field_element<F>();   // :58
             hs[q.chal_slot + per * i] = r;
             running_claim = fe_add<F>(a0, fe_mul<F>(r, fe_sub<F>(a1, a0)));
-            mb_put(i == 0 ? mb->chal : mb->aux[i - 1], r);
+            for (int k = 0; k < F::N; k++) __atomic_store_n(&mb->ans4[i][1 + k], r.l[k], __ATOMIC_RELAXED);
             for (size_t j = 0; j < half; j++) S[j] = fe_add<F>(S[j], fe_mul<F>(r, fe_sub<F>(S[half + j], S[j])));   // :61-63
             n = half;
+        }
+        for (int i = 0; i < m; i++) {                                          // the answer lines' tags last (dev_transcript.cuh)
+            __atomic_store_n(&mb->ans4[i][0], (uint32_t)seq, __ATOMIC_RELEASE);
+            __atomic_store_n(&mb->ans4[i][15], (uint32_t)seq, __ATOMIC_RELEASE);
         }
     }
     void serve_link(const Req &q) {                                            // gkr_protocol.rs:125-132
@@ -342,7 +346,7 @@ template <class F> struct DeviceRounds {
             }
             if (q.kind == kRound) serve_round(q, seq);           // publishes its answer itself, as early as it can
             else {
-                if (q.kind == kMulti) serve_multi(q);
+                if (q.kind == kMulti) serve_multi(q, seq);
                 else if (q.kind == kLink) serve_link(q);
                 else for (int k = 0; k < q.ntab; k++) hs[q.fin_slot + k] = mb_get(mb->fin + 12 * k);
                 __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
