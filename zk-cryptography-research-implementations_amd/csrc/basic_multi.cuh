@@ -22,7 +22,16 @@ __global__ void __launch_bounds__(kBlock) seg_sums_kernel(const void *__restrict
     const unsigned seg = blockIdx.x / bps, bq = blockIdx.x % bps;
     const size_t base = (size_t)seg * seglen, stride = (size_t)bps * blockDim.x;
     Wide<F> acc[1] = {wide_zero<F>()};
-    for (size_t t = (size_t)bq * blockDim.x + threadIdx.x; t < seglen; t += stride) wide_add_fe<F>(acc[0], fe_load<F>(in, base + t));
+    size_t t = (size_t)bq * blockDim.x + threadIdx.x;
+    for (; t + 3 * stride < seglen; t += 4 * stride) {       // four loads in flight per lane
+        const Fe<F> x0 = fe_load<F>(in, base + t), x1 = fe_load<F>(in, base + t + stride);
+        const Fe<F> x2 = fe_load<F>(in, base + t + 2 * stride), x3 = fe_load<F>(in, base + t + 3 * stride);
+        wide_add_fe<F>(acc[0], x0);
+        wide_add_fe<F>(acc[0], x1);
+        wide_add_fe<F>(acc[0], x2);
+        wide_add_fe<F>(acc[0], x3);
+    }
+    for (; t < seglen; t += stride) wide_add_fe<F>(acc[0], fe_load<F>(in, base + t));
     Fe<F> tot;
     if (block_reduce_wide<F, 1>(acc, sh, tot)) fe_store<F>(partials, blockIdx.x, tot);
 }
