@@ -124,3 +124,73 @@ def test_sharded_kzg_open_and_commit(world, logn, backend):
         assert np.array_equal(res["proofs"], want_proofs)
         assert np.array_equal(res["commit"], want_commit)
         assert res["backend"].tobytes() == (b"rccl" if backend == "nccl" else b"host-ops")
+
+
+def test_rounds_handle_several_rounds_per_pass_and_its_argument_checks():
+    """zk_rounds_multi_* (include/zkmle.h): a host driving its own loop gets the oracle's proof, and misuse is refused with ZK_E_ARG"""
+    import ctypes as C
+    import numpy as np
+    import __graft_entry__ as G
+    from oracle import oracle as O
+    zk = G.import_package()
+    from zkmle_amd import _lib as L
+    lib = zk.lib()
+    L.check(lib.zk_init(0))
+    vp, u64p = C.c_void_p, L.u64p
+    lib.zk_rounds_new.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(vp)]
+    lib.zk_rounds_free.argtypes = [vp]
+    lib.zk_rounds_limbs_len.argtypes = [vp]
+    lib.zk_rounds_limbs_len.restype = C.c_size_t
+    lib.zk_rounds_multi_max.argtypes = [vp]
+    lib.zk_rounds_multi_max.restype = C.c_uint
+    lib.zk_rounds_multi_evals.argtypes = [vp, vp, C.c_uint, vp]
+    lib.zk_rounds_multi_absorb.argtypes = [vp, vp, C.c_uint]
+    lib.zk_rounds_multi_fold_evals.argtypes = [vp, vp, vp, C.c_uint, C.c_uint, vp]
+    lib.zk_rounds_multi_tail.argtypes = [vp, vp]
+    lib.zk_rounds_collect.argtypes = [vp, vp, u64p, u64p, u64p, u64p]
+    field, logn = 0, 15
+    n = 1 << logn
+    poly = zk.MultilinearPolynomial.random(field, n, 0xABC)
+    table = poly.evaluated_values
+    tr = zk.Transcript()
+    tr.append(O.mle_to_bytes(field, table))                       # prover.rs:38-39, as the caller of the handle does it
+    r = vp()
+    L.check(lib.zk_rounds_new(field, 0, 1, 1, logn, tr._h, C.byref(r)))
+    kmax = lib.zk_rounds_multi_max(r)
+    if kmax == 0:                                                 # ZK_HOST_TRANSCRIPT=0 in the environment: the one-round sequence applies
+        lib.zk_rounds_free(r)
+        pytest.skip("the transcript step runs on the device in this environment")
+    assert kmax == 4
+    assert lib.zk_rounds_limbs_len(r) * 8 <= 64 * 32
+    limbs = zk.MultilinearPolynomial.alloc(field, 64)             # device scratch for the limb words
+    lp = lib.zk_table_device_ptr(limbs._h)
+    t1 = zk.MultilinearPolynomial.alloc(field, n >> 3)
+    t2 = zk.MultilinearPolynomial.alloc(field, n >> 4)
+    E = L.ZK_E_ARG
+    assert lib.zk_rounds_multi_evals(r, poly._h, 5, lp) == E          # more rounds than the handle runs per pass
+    assert lib.zk_rounds_multi_evals(r, poly._h, 0, lp) == E
+    assert lib.zk_rounds_multi_fold_evals(r, poly._h, t1._h, 3, 0, lp) == E   # nothing absorbed yet
+    assert lib.zk_rounds_multi_tail(r, poly._h) == E                  # too long for the tail
+    L.check(lib.zk_rounds_multi_evals(r, poly._h, 3, lp))             # 15 rounds = 3 + 1 + 11
+    L.check(lib.zk_rounds_multi_absorb(r, lp, 3))
+    assert lib.zk_rounds_multi_fold_evals(r, poly._h, t1._h, 4, 0, lp) == E   # only 3 rounds absorbed
+    assert lib.zk_rounds_multi_fold_evals(r, poly._h, poly._h, 3, 0, lp) == E # in place
+    L.check(lib.zk_rounds_multi_fold_evals(r, poly._h, t1._h, 3, 1, lp))
+    L.check(lib.zk_rounds_multi_absorb(r, lp, 1))
+    L.check(lib.zk_rounds_multi_fold_evals(r, t1._h, t2._h, 1, 0, None))
+    assert lib.zk_rounds_multi_tail(r, t1._h) == E                    # wrong table (too long, and the round count would not add up)
+    L.check(lib.zk_rounds_multi_tail(r, t2._h))
+    nl = zk.limbs(field)
+    cs, rp, ch = np.zeros(nl, np.uint64), np.zeros((logn, 2, nl), np.uint64), np.zeros((logn, nl), np.uint64)
+    L.check(lib.zk_rounds_collect(r, tr._h, L.p64(cs), L.p64(rp), L.p64(ch), None))
+    lib.zk_rounds_free(r)
+    ecs, erp, ech = O.sumcheck_basic_prove(field, table)
+    assert np.array_equal(cs, ecs) and np.array_equal(rp.reshape(erp.shape), erp) and np.array_equal(ch.reshape(ech.shape), ech)
+    assert np.array_equal(poly.evaluated_values, table)               # the caller's table is never folded in place
+    # a GKR-sumcheck handle (mode 1) does not offer it
+    r2 = vp()
+    t2r = zk.Transcript()
+    L.check(lib.zk_rounds_new(field, 1, 2, 2, 4, t2r._h, C.byref(r2)))
+    assert lib.zk_rounds_multi_max(r2) == 0
+    assert lib.zk_rounds_multi_evals(r2, poly._h, 2, lp) == E
+    lib.zk_rounds_free(r2)
