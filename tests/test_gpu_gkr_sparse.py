@@ -171,3 +171,34 @@ def test_wide_circuits_bit_identical_to_generalised_dense_model(zk, shape):
         assert zk.to_ints(f, proof.wb_evals) == want["wb"] and zk.to_ints(f, proof.wc_evals) == want["wc"]
         assert zk.to_ints(f, proof.claimed_sum.reshape(1, -1)) == [want["claimed_sum"]]
         assert zk.gkr.sparse_verify(f, rows, out_bits, proof, x) is True
+
+
+def test_skewed_wiring_bit_identical_to_generalised_dense_model(zk):
+    """Most gates of a layer share ONE left (resp. right) index: the grouped gate list has runs far longer than the 256 gates a pass of
+    the gate-parallel table kernels stages (csrc/zkmle_gkr_sparse.hip grouped_pair_sums), next to many empty groups."""
+    from oracle import pymodel as M
+    f, out_bits, in_last = 0, [6, 6], 6
+    p = O.modulus(f)
+    rng = random.Random(77)
+    spec = []
+    for l in range(2):
+        seen = set()
+        hot = rng.randrange(64)
+        while len(seen) < 700:                                  # 700 gates under one left index
+            seen.add((hot, rng.randrange(64), rng.randrange(64), rng.choice([0, 1])))
+        hot_r = rng.randrange(64)
+        while len(seen) < 1300:                                 # 600 more under one right index
+            seen.add((rng.randrange(64), hot_r, rng.randrange(64), rng.choice([0, 1])))
+        for _ in range(60):
+            seen.add((rng.randrange(64), rng.randrange(64), rng.randrange(64), rng.choice([0, 1])))
+        spec.append(sorted(seen, key=lambda g: (g[2], g[0], g[1], g[3])))
+    xs = [rng.randrange(p) for _ in range(1 << in_last)]
+    want = M.gkr_prove_wide(spec, out_bits, xs, p)
+    rows = [np.array(layer, np.uint64).reshape(-1, 4) for layer in spec]
+    x = zk.from_ints(f, xs)
+    proof = zk.gkr.sparse_prove(f, rows, out_bits, x)
+    assert zk.to_ints(f, proof.circuit_output) == want["circuit_output"]
+    assert [zk.to_ints(f, c) for c in proof.coeffs] == want["coeffs"]
+    assert zk.to_ints(f, proof.challenges) == want["challenges"]
+    assert zk.to_ints(f, proof.wb_evals) == want["wb"] and zk.to_ints(f, proof.wc_evals) == want["wc"]
+    assert zk.gkr.sparse_verify(f, rows, out_bits, proof, x) is True
