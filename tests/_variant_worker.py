@@ -81,6 +81,23 @@ def main():
     checked += 1
     if not zk.gkr.sparse_verify(0, rows, [lg] * depth, proof, x):
         bad.append(["sparse_gkr_verify", lg, depth])
+    # the same with skewed wiring: thousands of gates under one left / one right index (several passes of the gate-parallel table kernels)
+    lg2 = 13
+    n2 = 1 << lg2
+    rows2 = []
+    for _ in range(2):
+        g = np.zeros((n2, 4), np.uint64)
+        g[:, 0] = rng.integers(0, n2, n2); g[:, 1] = rng.integers(0, n2, n2); g[:, 2] = rng.integers(0, n2, n2); g[:, 3] = rng.integers(0, 2, n2)
+        g[: n2 // 2, 0] = 77
+        g[n2 // 4: 3 * n2 // 4, 1] = 4321
+        rows2.append(g)
+    x2 = rand_table(0, n2, 4343)
+    proof2 = zk.gkr.sparse_prove(0, rows2, [lg2] * 2, x2)
+    for arr in (proof2.circuit_output, proof2.coeffs, proof2.challenges, proof2.wb_evals, proof2.wc_evals):
+        h.update(np.ascontiguousarray(arr).tobytes())
+    checked += 1
+    if not zk.gkr.sparse_verify(0, rows2, [lg2] * 2, proof2, x2):
+        bad.append(["sparse_gkr_verify_skewed", lg2])
     print(json.dumps({"checked": checked, "mismatches": bad, "sparse_gkr_digest": h.hexdigest(), "env": {k: v for k, v in os.environ.items() if k.startswith("ZK_")}}), flush=True)
 
 
