@@ -216,6 +216,27 @@ template <class F> ZK_HD Ufe<F> umul2(const Ufe<F> &a1, const Ufe<F> &b1, const 
     }
     return u_normalize_columns<F>(T);
 }
+// (a1 * b1 + a2 * b2) / 2^(32 N) mod p for stored-form right operands (the digits of b << SH are scanned, as in umul_std): the sum of two
+// stored-form products as ONE scan with one Montgomery reduction per row.  For canonical operands (all four < p) the result is below
+// 2 p^2 / 2^(32 N) + p < 2 p (p < 2^(32 N - 1) for the four moduli), so one conditional subtraction finishes it.
+template <class F> ZK_HD Ufe<F> umul2_std(const Ufe<F> &a1, const Fe<F> &b1, const Ufe<F> &a2, const Fe<F> &b2) {
+    constexpr int L = UParams<F>::L;
+    uint64_t T[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) T[j] = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        const uint32_t d1 = u_digit_std<F>(b1, i);
+#pragma unroll
+        for (int j = 0; j < L; j++) T[j] += (uint64_t)a1.l[j] * d1;
+        u_row<F>(T, a2, u_digit_std<F>(b2, i));
+    }
+    return u_normalize_columns<F>(T);
+}
+// a1 * b1 + a2 * b2 in the stored form, canonical: bit-identical to fe_add(fe_mul(a1, b1), fe_mul(a2, b2))
+template <class F> ZK_HD Fe<F> fe_mul2_u(const Fe<F> &a1, const Fe<F> &b1, const Fe<F> &a2, const Fe<F> &b2) {
+    return u_to_limbs32<F>(u_reduce_once<F>(umul2_std<F>(u_from_limbs32<F>(a1), b1, u_from_limbs32<F>(a2), b2)));
+}
 // a^2 / 2^(29 L): the row scan with the symmetric products taken once.  At step t the live column j holds
 // absolute weight j + t, so a_j a_t (j > t) is added doubled at step t only; every contribution to the column
 // that the Montgomery step consumes (weight t) comes from steps <= t/2, so T[0] is complete when it is used.

@@ -92,9 +92,8 @@ template <class F> __device__ __forceinline__ Fe<F> other_entry(const OtherTable
 template <class F> __device__ __forceinline__ Fe<F> gate_weight(const GateWeights &g, uint32_t idx) {
     if (g.w) return fe_load<F>(g.w, idx);
     const uint32_t h = idx >> g.lbits, l = idx & ((1u << g.lbits) - 1u);
-    Fe<F> v = fe_mul<F>(fe_load<F>(g.ah, h), fe_load<F>(g.al, l));
-    if (g.bh) v = fe_add<F>(v, fe_mul<F>(fe_load<F>(g.bh, h), fe_load<F>(g.bl, l)));
-    return v;
+    if (g.bh) return fe_mul2_u<F>(fe_load<F>(g.ah, h), fe_load<F>(g.al, l), fe_load<F>(g.bh, h), fe_load<F>(g.bl, l));   // one reduction for both products
+    return fe_mul<F>(fe_load<F>(g.ah, h), fe_load<F>(g.al, l));
 }
 struct Phase1Op {            // per gate: w and t = w W[right]; add gate: H1 += w, H0 += t; mul gate: H1 += t
     template <class F> static __device__ __forceinline__ void terms(const Fe<F> &wg, const Fe<F> &t, uint32_t op, Fe<F> &x, Fe<F> &y) {
