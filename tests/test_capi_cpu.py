@@ -85,6 +85,20 @@ def test_host_helpers_match_oracle(zk, field):
         assert L.zk_fe_from_le_bytes_mod_order(field, buf.ctypes.data_as(C.POINTER(C.c_uint8)), nb,
                                                out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
         assert np.array_equal(out, O.from_le_bytes_mod_order(field, data))
+    # the short-input path (a few subtractions + one product, csrc/host_field.h): multiples of p and their neighbours, full-width values
+    width = 8 * n
+    edge = [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p, 2 * p + 1, (1 << (8 * width)) - 1, (1 << (8 * width)) - p]
+    edge += [k * p + d for k in range(3, 16) for d in (-1, 0, 1) if 0 <= k * p + d < (1 << (8 * width))]
+    for v in edge:
+        for nb in (width, 32) if width != 32 else (32,):
+            if v >= 1 << (8 * nb):
+                continue
+            data = v.to_bytes(nb, "little")
+            buf = np.frombuffer(data, np.uint8).copy()
+            out = np.zeros(n, np.uint64)
+            assert L.zk_fe_from_le_bytes_mod_order(field, buf.ctypes.data_as(C.POINTER(C.c_uint8)), nb,
+                                                   out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+            assert zk.to_ints(field, out.reshape(1, -1)) == [v % p], (field, hex(v), nb)
     m = O.from_ints(field, [vals[5]])[0]
     be = np.zeros(8 * n, np.uint8)
     assert L.zk_fe_to_bytes_be(field, m.ctypes.data_as(C.POINTER(C.c_uint64)), be.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
