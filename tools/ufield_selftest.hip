@@ -1,5 +1,5 @@
 // ufield_selftest.hip -- host-side self-test of the unsaturated 29-bit-limb arithmetic (csrc/ufield.cuh): the
-// drop-in product, the internal-form product / squaring, the unreduced add / sub and the conversions against the
+// drop-in product, the internal-form product / squaring, the dual product, the unreduced add / sub and the conversions against the
 // saturated CIOS reference, for all four fields, on random and edge operands.  Runs on the CPU (the functions are
 // __host__ __device__); the GPU code path is covered bit-exactly by tests -m gpu.
 #include "../zk-cryptography-research-implementations_amd/csrc/ufield.cuh"
@@ -29,6 +29,11 @@ template <class F> int test(const char* name){
     Fe<F> xs = u_to_std<F>(umul<F>(x, one_u));
     Fe<F> ws = fe_sub<F>(fe_add<F>(fe_sqr<F>(a), want), fe_dbl<F>(want));
     if (!fe_eq<F>(xs, ws)) { if(bad<3) printf("%s chain mismatch it=%d\n",name,it); bad++; }
+    // two stored-form products in one scan with one reduction (sparse GKR gate weights): a b + c d, operands up to p - 1 each
+    Fe<F> c = random_element<F>(3, it), dd = random_element<F>(4, it);
+    if (it==1){ c=a; dd=b; }                                   // (p-1)(p-1) + (p-1)(p-1): the largest sum
+    Fe<F> w2 = fe_add<F>(want, fe_mul_cios<F>(c,dd)), g2 = fe_mul2_u<F>(a,b,c,dd);
+    if (!fe_eq<F>(w2,g2)) { if(bad<3) printf("%s mul2 mismatch it=%d\n",name,it); bad++; }
   }
   printf("%s: %s\n", name, bad? "FAIL":"ok"); return bad;
 }
