@@ -160,12 +160,20 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         msm_scan_apply_kernel<<<ntiles, kScanTile, 0, cur_stream()>>>(d_totals, nbuckets, seg_len, (const uint64_t *)te.p, (const uint32_t *)ts.p,
                                                      (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipStreamSynchronize(cur_stream()));
     }
+    // the three totals the host needs to size what follows: both copies into pinned staging, ONE synchronisation (three before: ~60 us of
+    // a 2^20-term MSM)
     uint64_t entries = 0;
     uint32_t tail[2] = {0, 0};                              // {segments, largest per-bucket segment count}
-    ZK_HIP(zk::memcpy_on_stream(&entries, (uint64_t *)starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
-    ZK_HIP(zk::memcpy_on_stream(tail, (uint32_t *)seg_starts.p + nbuckets, 8, hipMemcpyDeviceToHost));
+    {
+        void *stage = nullptr;
+        ZK_TRY(host_staging(16, &stage));
+        ZK_HIP(hipMemcpyAsync(stage, (uint64_t *)starts.p + nbuckets, 8, hipMemcpyDeviceToHost, cur_stream()));
+        ZK_HIP(hipMemcpyAsync((char *)stage + 8, (uint32_t *)seg_starts.p + nbuckets, 8, hipMemcpyDeviceToHost, cur_stream()));
+        ZK_HIP(hipStreamSynchronize(cur_stream()));         // (also: the scan's temporaries are freed on scope exit above)
+        memcpy(&entries, stage, 8);
+        memcpy(tail, (char *)stage + 8, 8);
+    }
     uint32_t nseg = tail[0], max_segs = tail[1];
     ZK_TRY(sorted.alloc((entries ? entries : 1) * 4));
     static const int two_level_bits = [] { const char *e = getenv("ZK_MSM_TWO_LEVEL_BITS"); int k = e ? atoi(e) : 20; return k < 12 ? 12 : k; }();
