@@ -464,7 +464,7 @@ int launch_msm_weighted_tail(void *X, void *Y, unsigned narrays, unsigned mbits,
 int launch_msm_window_sums(const void *A, const void *R, unsigned nwin, unsigned c, void *out, hipStream_t s);
 int launch_g1_bases_to_u(const void *affine, size_t n, void *out_u, hipStream_t s);
 int launch_g1_shift(const void *in, int in_is_xyzz, size_t n, unsigned c, void *out_xyzz, hipStream_t s);   // out = 2^c * in (stored affine or XYZZ in)
-int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, hipStream_t s);
+int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, void *B, hipStream_t s);
 int launch_msm_reduce_level(void *A, void *R, unsigned nwin, unsigned c, size_t half, hipStream_t s);
 int launch_g1_pair_add(const void *in_affine, size_t half, void *out_xyzz, hipStream_t s);
 int launch_g1_pair_add_xyzz(const void *in_xyzz, size_t half, void *out_xyzz, hipStream_t s);

@@ -29,8 +29,9 @@ __global__ void __launch_bounds__(256) msm_partials_regroup_kernel(const void *_
 
 // bucket (w, b) = sum of its segments' partials, written to slot b of window w in the 2^(c-1)-slot reduction array A
 // (slot b holds digit magnitude b + 1)
+// (every slot is written, empty buckets as infinity; `B`, when given, receives the same values: the copy the two-stage reduction folds over l)
 __global__ void __launch_bounds__(256) msm_bucket_combine_kernel(const void *__restrict__ partials, const uint32_t *__restrict__ seg_starts,
-                                          unsigned nwin, unsigned c, void *__restrict__ A) {
+                                          unsigned nwin, unsigned c, void *__restrict__ A, void *__restrict__ B) {
     unsigned nb = 1u << (c - 1);
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (size_t)nwin * nb) return;
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(256) msm_bucket_combine_kernel(const void *__r
     G1XyzzU acc = g1u_inf();
     for (uint32_t s = s0; s < s1; s++) acc = g1u_add(acc, g1u_load_xyzz(partials, s));
     g1u_store_xyzz(A, ((size_t)w << (c - 1)) + b, acc);
+    if (B) g1u_store_xyzz(B, ((size_t)w << (c - 1)) + b, acc);
 }
 
 // step 4: one halving level of  sum_b b A[b]  over the 2^(c-1) slots of every window, in place (half = current length / 2):
@@ -166,9 +168,9 @@ int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_star
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
-int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, hipStream_t s) {
+int launch_msm_bucket_combine(const void *partials, const uint32_t *seg_starts, unsigned nwin, unsigned c, void *A, void *B, hipStream_t s) {
     size_t nbuckets = (size_t)nwin << (c - 1);
-    msm_bucket_combine_kernel<<<(unsigned)((nbuckets + 255) / 256), 256, 0, s>>>(partials, seg_starts, nwin, c, A);
+    msm_bucket_combine_kernel<<<(unsigned)((nbuckets + 255) / 256), 256, 0, s>>>(partials, seg_starts, nwin, c, A, B);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }

@@ -213,8 +213,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     size_t red_bytes = ((size_t)nwin << (c - 1)) * kXyzzUBytes;
     ZK_TRY(A.alloc(red_bytes));
     ZK_TRY(R.alloc(red_bytes));
-    ZK_HIP(hipMemsetAsync(A.p, 0, red_bytes, cur_stream()));     // all-zero XYZZ = infinity (ZZ = 0)
-    if (c < 6) ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, cur_stream()));
+    if (c < 6) ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, cur_stream()));     // all-zero XYZZ = infinity (ZZ = 0); A (and, c >= 6, R) are written whole by the combine kernel
     if (nseg) {
         ZK_TRY(launch_msm_bucket_sum(d_bases, (const uint32_t *)sorted.p, (const uint64_t *)starts.p, (const uint32_t *)seg_starts.p,
                                      nbuckets, seg_len, nseg, partials.p, cur_stream()));
@@ -239,13 +238,12 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         cur_starts = (const uint32_t *)ns.p;
         max_segs = tail[1];
     }
-    ZK_TRY(launch_msm_bucket_combine(cur_partials, cur_starts, nwin, (unsigned)c, A.p, cur_stream()));
+    ZK_TRY(launch_msm_bucket_combine(cur_partials, cur_starts, nwin, (unsigned)c, A.p, c >= 6 ? R.p : nullptr, cur_stream()));
     ZK_TRY(ev.mark());
     std::vector<G1Xyzz> sums(nwin);
     if (c >= 6) {
         // two-stage weighted bucket sum (msm_reduce.hip): slot b = h L + l weighs b + 1 = L h + (l + 1)
         const unsigned cm1 = (unsigned)c - 1, k = cm1 / 2, hb = cm1 - k, mbits = hb > k ? hb : k;
-        ZK_HIP(hipMemcpyAsync(R.p, A.p, red_bytes, hipMemcpyDeviceToDevice, cur_stream()));      // the copy that reduces over l
         for (unsigned lvl = 0; lvl < mbits; lvl++) {
             size_t hh = lvl < hb ? ((size_t)1 << (hb - 1 - lvl)) : 0, lh = lvl < k ? ((size_t)1 << (k - 1 - lvl)) : 0;
             ZK_TRY(launch_msm_plain_level(A.p, R.p, nwin, cm1, k, hh, lh, cur_stream()));
