@@ -316,6 +316,7 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
     TableSet ping, pong;
     std::vector<const zk_table *> cur(tabs, tabs + ntab);
     bool absorbed = false;                                               // the evaluations of `cur` are in the transcript
+    const size_t round_words = (mode == 0 ? 2 : nfac + 1) * ((size_t)field_limbs64(field) * 2 + 1);   // one round's evaluations as limb words
     const unsigned kmax = mode == 0 ? zk_rounds_multi_max(r) : 0u;
     if (kmax > 0) {
         // basic sumcheck, several rounds per pass and per all-reduce (basic_multi.cuh): the top-bit segments of the global table are
@@ -363,13 +364,13 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
         ZK_TRY(ping.alloc(field, L / 2, ntab));
         ZK_TRY(pong.alloc(field, L / 4 ? L / 4 : 1, ntab));
         ZK_TRY(zk_rounds_evals(r, cur.data(), lp));
-        ZK_TRY(c->all_reduce_i64(lp, zk_rounds_limbs_len(r)));           // the round's only exchange, on the stream
+        ZK_TRY(c->all_reduce_i64(lp, round_words));           // the round's only exchange, on the stream
         ZK_TRY(zk_rounds_absorb(r, lp));
         absorbed = true;
         TableSet *dst = &ping, *other = &pong;
         while (L * G > kTail) {                                          // local rounds: fold + next evaluations, all-reduce, transcript
             ZK_TRY(zk_rounds_fold_evals(r, cur.data(), dst->t.data(), lp));
-            ZK_TRY(c->all_reduce_i64(lp, zk_rounds_limbs_len(r)));
+            ZK_TRY(c->all_reduce_i64(lp, round_words));
             ZK_TRY(zk_rounds_absorb(r, lp));
             for (size_t k = 0; k < ntab; k++) cur[k] = dst->t[k];
             TableSet *x = dst; dst = other; other = x;
@@ -379,7 +380,7 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
     if (G == 1) {                                                        // the local table IS the global table
         if (!absorbed) {
             ZK_TRY(zk_rounds_evals(r, cur.data(), lp));
-            ZK_TRY(c->all_reduce_i64(lp, zk_rounds_limbs_len(r)));       // a one-rank RCCL communicator still runs its collective
+            ZK_TRY(c->all_reduce_i64(lp, round_words));       // a one-rank RCCL communicator still runs its collective
             ZK_TRY(zk_rounds_absorb(r, lp));
         }
         ZK_TRY(zk_rounds_tail(r, cur.data()));
