@@ -1,16 +1,22 @@
 """bench.py -- field-mul/s of the 2^24 MLE fold + G1-add/s of the 2^24 MSM (BASELINE.json metric) on N MI355X GPUs.
 
-A step = one `partial_evaluate(table, 0, r)` pass (evaluation_form.rs:61-106) over one resident BLS12-381 Fr table per GPU
-(2^23 field multiplications per 2^24-entry table, 96 algorithmic bytes each).
+A step = one `partial_evaluate(table, 0, r)` pass (evaluation_form.rs:61-106) over a resident BLS12-381 Fr table
+(one field multiplication and 96 algorithmic bytes per output entry).
 
-  --scaling weak   (default) every rank folds its own 2^24-entry low-bit shard; no data-path collective.
-  --scaling strong BASELINE config 5: ONE 2^24-entry table low-bit-sharded N ways (2^24 / N entries per rank).
-Either way the line also carries, under "config5_strong", config 5 verbatim at this N: the sharded sumcheck prover of the 2^24
-table (Prover::prove rounds, prover.rs:46-63; one RCCL all-reduce per large round, whole-table absorb off) and the 2^24-term
-MSM slice-sharded N ways (multilinear_kzg.rs:37-42; one all-gather of N points), and under "msm" the per-GPU 2^24 MSM.
+  N = 1   the 2^24-entry table on the one GPU (2^23 field-mul per step).
+  N > 1   BASELINE config 5, strong scaling (the default): ONE 2^24-entry table low-bit-sharded N ways, every rank
+          folds its 2^24 / N entries per step -- `value` = 2^23 x K / time, with the whole sharded sumcheck proof of that table
+          (Prover::prove rounds, prover.rs:46-63; one all-reduce per pass) and the 2^24-term MSM slice-sharded N ways
+          (multilinear_kzg.rs:37-42; one all-gather of N points) beside it under "config5_strong".  `--scaling weak` makes the
+          headline a 2^24 table per GPU instead; by default that run is the secondary key "weak".
+The line also carries "msm" (one 2^24-term MSM per GPU) and, at N = 1, "configs": BASELINE configs 2, 3 and 4 timed and checked.
+Everything that is timed is checked afterwards: the fold against the oracle on sampled entries, every proof through the
+verifier's equations, every MSM through the O(N) identity of its structured bases.
 
 `python bench.py --gpus N` with WORLD_SIZE unset starts the N ranks itself (child processes, one per GPU, before anything
 touches a GPU in this process); under torchrun (WORLD_SIZE set) it is one rank and fails unless WORLD_SIZE == --gpus.
+`--rehearse` runs the N-rank code path on ONE GPU with the ranks as threads of this process (a one-GPU box allows at most 6
+processes on its card, config 5 has 8 ranks), collectives over the library's ranks-as-threads transport.
 Prints ONE JSON line on rank 0.  See DESIGN.md section 5 for the roofline accounting.
 """
 import argparse
@@ -20,6 +26,7 @@ import socket
 import statistics
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 SEED_TABLE, SEED_MSM = 0x5EED0005, 0x5EED0003
 MSM_D = 0x9E3779B97F4A7C15
+HBM_PEAK_GBPS = 8000.0                                       # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def parse_args():
@@ -35,14 +43,18 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--log-n", type=int, default=24)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="N > 1 only; default strong = BASELINE config 5 (ONE table sharded N ways)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-msm", action="store_true", help="skip the per-GPU 2^log-n MSM leg")
-    ap.add_argument("--no-config5", action="store_true", help="skip the strong-scaling config-5 legs")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 legs (sharded proof + sharded MSM)")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2, 3, 4 (N = 1 only)")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling fold")
     ap.add_argument("--msm-reps", type=int, default=3)
-    ap.add_argument("--require-rccl", action="store_true", help="exit non-zero unless the collectives ran over RCCL")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="exit non-zero unless the collectives ran over RCCL and every config-5 leg succeeded")
     ap.add_argument("--rehearse", action="store_true",
-                    help="debug: run the N>1 code path with every rank on cuda:0 over gloo (one-GPU boxes)")
+                    help="debug: the N > 1 code path with every rank a thread of this process on cuda:0 (one-GPU boxes)")
     return ap.parse_args()
 
 
@@ -80,61 +92,102 @@ def launch_ranks(args):
     return rc
 
 
+class RankEnv:
+    """One rank's view of the job: who it is, how it meets the other ranks (torch.distributed between processes, a thread
+    barrier between the threads of a rehearsal), and its end of the provers' communicator."""
+
+    def __init__(self, rank, world, comm, collectives, dist=None, tgroup=None):
+        self.rank, self.world, self.comm, self.collectives = rank, world, comm, collectives
+        self.dist, self.tgroup = dist, tgroup
+
+    def barrier(self):
+        if self.world == 1:
+            return
+        if self.tgroup is not None:
+            self.tgroup["barrier"].wait()
+        else:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        if self.tgroup is not None:
+            slots = self.tgroup["slots"]
+            slots[self.rank] = float(x)
+            self.tgroup["barrier"].wait()
+            m = max(slots)
+            self.tgroup["barrier"].wait()
+            return m
+        import torch
+        tt = torch.tensor([x], device="cpu" if self.dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def timed(self, fn, reps):
+        """max over ranks of the mean wall time of `fn` over `reps` calls between barriers; -> (seconds, last result)"""
+        import torch
+        self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = [fn() for _ in range(reps)]
+        torch.cuda.synchronize()
+        self.barrier()
+        dt = (time.perf_counter() - t0) / reps
+        return self.max_over_ranks(dt), outs[-1]
+
+
 def main():
     args = parse_args()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if args.gpus > 1 and args.gpus & (args.gpus - 1):
+        raise SystemExit("bench.py: the table shards by low index bits, --gpus must be a power of two")
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={os.environ['WORLD_SIZE']} but --gpus {args.gpus}: refusing to report a line for the wrong rank count")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.rehearse:
         sys.exit(launch_ranks(args))
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
 
     if os.environ.get("ZK_BENCH_WATCHDOG"):                   # diagnostics: dump every thread's stack and exit if a rank is stuck
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["ZK_BENCH_WATCHDOG"]), exit=True)
-    import numpy as np
     import torch
-    import torch.distributed as dist
-
     import __graft_entry__ as G
     zk = G.import_package()
     from zkmle_amd import _lib
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: zkmle_amd has no CPU fallback")
 
+    if args.rehearse and args.gpus > 1:
+        return rehearse_threads(args, zk)
+
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a line for the wrong rank count")
-    if world & (world - 1):
-        raise SystemExit("bench.py: the table shards by low index bits, --gpus must be a power of two")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: zkmle_amd has no CPU fallback")
-    if args.rehearse:
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     _lib.check(zk.lib().zk_init(local_rank))
     collectives = {"backend": "none (one rank)", "library": None, "note": None}
+    device = None
     if world > 1:
-        if args.rehearse:
-            dist.init_process_group("gloo")
-            collectives = {"backend": "gloo (rehearsal: every rank on cuda:0)", "library": None, "note": "not an RCCL measurement"}
-        else:
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            probe = torch.zeros(1, device="cuda")
+            dist.all_reduce(probe)                      # the first collective builds the communicator: fail here, not mid-run
+            torch.cuda.synchronize()
+            collectives = {"backend": "nccl (RCCL over xGMI)", "library": None, "note": None}
+            device = torch.device("cuda", local_rank)
+        except Exception as e:                          # noqa: BLE001
+            if args.require_rccl:
+                raise SystemExit(f"bench.py --require-rccl: nccl (RCCL) process group failed: {e!r}")
+            note = f"nccl (RCCL) unavailable, collectives over gloo with host staging: {e!r}"[:300]
             try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                probe = torch.zeros(1, device="cuda")
-                dist.all_reduce(probe)                      # the first collective builds the communicator: fail here, not mid-run
-                torch.cuda.synchronize()
-                collectives = {"backend": "nccl (RCCL over xGMI)", "library": None, "note": None}
-            except Exception as e:                          # noqa: BLE001
-                if args.require_rccl:
-                    raise SystemExit(f"bench.py --require-rccl: nccl (RCCL) process group failed: {e!r}")
-                note = f"nccl (RCCL) unavailable, collectives over gloo with host staging: {e!r}"[:300]
-                try:
-                    dist.destroy_process_group()
-                except Exception:                           # noqa: BLE001
-                    pass
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                dist.init_process_group("gloo")
-                args.rehearse = True                        # host-staged tensors from here on (each rank keeps its own GPU)
-                collectives = {"backend": "gloo (FALLBACK, host staged)", "library": None, "note": note}
-    S = zk.sharded
-    comm = S.Comm(device=None if (args.rehearse or world == 1) else torch.device("cuda", local_rank))
+                dist.destroy_process_group()
+            except Exception:                           # noqa: BLE001
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            dist.init_process_group("gloo")
+            collectives = {"backend": "gloo (FALLBACK, host staged)", "library": None, "note": note}
+    comm = zk.sharded.Comm(device=device)
     if world > 1:
         collectives["library"] = comm.native_backend()      # "rccl": the library's own ncclCommInitRank communicator
         if comm.native_note:                                # it could not be created: the provers' exchange goes over gloo, loudly
@@ -142,25 +195,81 @@ def main():
             collectives["backend"] += " + gloo (FALLBACK for the provers' exchange, host staged)"
         if args.require_rccl and collectives["library"] != "rccl":
             raise SystemExit("bench.py --require-rccl: the provers' communicator is not RCCL")
+    env = RankEnv(rank, world, comm, collectives, dist=dist)
+    result = run_rank(env, args, zk)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    comm.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if result.get("failed_legs") and args.require_rccl:
+        raise SystemExit("bench.py --require-rccl: a config-5 leg failed: " + ", ".join(result["failed_legs"]))
 
-    field = zk.FR381
-    n_global = 1 << args.log_n
-    strong = args.scaling == "strong"
-    n = n_global // world if strong else n_global          # this rank's table
-    if n < 4:
-        raise SystemExit("table too small for this many ranks")
-    half = n // 2
-    MP = zk.MultilinearPolynomial
+
+def rehearse_threads(args, zk):
+    """The N-rank code path on one GPU: N threads of this process, each with its own HIP stream, exchanging through the
+    library's ranks-as-threads transport (include/zkmle.h zk_comm_local_group_*).  Not an RCCL measurement; says so."""
+    import ctypes as C
+    import torch
+    from zkmle_amd import _lib
+    world = args.gpus
+    group = zk.sharded.LocalGroup(world)
+    tgroup = {"barrier": threading.Barrier(world), "slots": [0.0] * world}
+    results, errors = [None] * world, []
+    collectives = {"backend": f"local-threads (rehearsal: {world} ranks as threads on cuda:0, host-staged exchanges)", "library": None,
+                   "note": "not an RCCL measurement: one GPU shared by every rank"}
+
+    def rank_main(rank):
+        comm = None
+        try:
+            torch.cuda.set_device(0)
+            lib = zk.lib()
+            _lib.check(lib.zk_init(0))
+            st = torch.cuda.Stream()
+            torch.cuda.set_stream(st)
+            lib.zk_set_stream.argtypes = [C.c_void_p]
+            _lib.check(lib.zk_set_stream(C.c_void_p(st.cuda_stream)))
+            comm = group.comm(rank)
+            coll = dict(collectives, library=comm.native_backend())
+            results[rank] = run_rank(RankEnv(rank, world, comm, coll, tgroup=tgroup), args, zk)
+        except BaseException as e:                        # noqa: BLE001
+            import traceback
+            errors.append((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+            group.abort()
+            tgroup["barrier"].abort()
+        finally:
+            try:
+                torch.cuda.synchronize()
+                zk.lib().zk_set_stream(None)
+                if comm is not None:
+                    comm.close()
+            except Exception:                             # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    group.close()
+    if errors:
+        for rank, tb in errors:
+            print(f"rank {rank} failed:\n{tb}", file=sys.stderr)
+        raise SystemExit(1)
+    print(json.dumps(results[0]), flush=True)
+
+
+# ---- the fold (headline) ------------------------------------------------------------------------------------------------
+def fold_leg(env, zk, n, seed, first, stride, r, steps, warmup, prewarm_s=0.4):
+    """K timed launches of partial_evaluate(table, 0, r) on this rank's n-entry table between barriers.  HIP events on the launch
+    stream, one every K/25 launches: mean over the timed region + median of the chunk means.  -> (numbers, table, out)"""
+    import torch
+    from zkmle_amd import _lib
     L = zk.lib()
-    table = MP.alloc(field, n)                               # shard-wise on-device generation
-    if strong:
-        first, stride, seed = rank, world, SEED_TABLE        # local j <- global j * world + rank of ONE table
-    else:
-        first, stride, seed = 0, 1, SEED_TABLE + rank        # an own table per rank
+    MP = zk.MultilinearPolynomial
+    table = MP.alloc(zk.FR381, n)                            # shard-wise on-device generation
     _lib.check(L.zk_table_fill_random_strided(table._h, seed, first, stride))
-    out = MP.alloc(field, half)
-    r = np.zeros(4, np.uint64)
-    _lib.check(L.zk_host_fill_random(field, SEED_TABLE, n_global, 1, _lib.p64(r)))
+    out = MP.alloc(zk.FR381, n // 2)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -169,217 +278,299 @@ def main():
     # clock pre-warm (untimed, outside the W / K protocol): a cold MI355X needs a few hundred milliseconds of
     # load before it holds its sustained clock; without this a short K reads 20 % low
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.4:
+    while time.perf_counter() - t_pre < prewarm_s:
         for _ in range(50):
             step()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    env.barrier()
     torch.cuda.synchronize()
-    # HIP events on the launch stream, one every `chunk` launches: mean over the timed region + median of >= 20 chunk means
-    chunk = max(1, args.steps // 25)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range((args.steps + chunk - 1) // chunk + 1)]
+    chunk = max(1, steps // 25)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range((steps + chunk - 1) // chunk + 1)]
     t0 = time.perf_counter()
     marks[0].record()
-    for k in range(args.steps):
+    for k in range(steps):
         step()
-        if (k + 1) % chunk == 0 or k + 1 == args.steps:
+        if (k + 1) % chunk == 0 or k + 1 == steps:
             marks[(k + chunk) // chunk].record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    env.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kern_ms = marks[0].elapsed_time(marks[-1]) / args.steps
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    kern_ms = marks[0].elapsed_time(marks[-1]) / steps
     per_chunk = []
     for i in range(len(marks) - 1):
-        cnt = min(chunk, args.steps - i * chunk)
+        cnt = min(chunk, steps - i * chunk)
         per_chunk.append(marks[i].elapsed_time(marks[i + 1]) / cnt)
-    kern_ms_median = statistics.median(per_chunk)
-    if world > 1:
-        tt = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    return {"dt": dt, "kernel_ms": kern_ms, "kernel_ms_median": statistics.median(per_chunk), "chunks": len(per_chunk)}, table, out
 
+
+def run_rank(env, args, zk):
+    import numpy as np
+    from zkmle_amd import _lib
+    rank, world = env.rank, env.world
+    field = zk.FR381
+    n_global = 1 << args.log_n
+    strong = args.scaling == "strong" and world > 1
+    n = n_global // world if strong else n_global          # this rank's table
+    if n < 4:
+        raise SystemExit("table too small for this many ranks")
+    half = n // 2
+    r = np.zeros(4, np.uint64)
+    _lib.check(zk.lib().zk_host_fill_random(field, SEED_TABLE, n_global, 1, _lib.p64(r)))
+    if strong:
+        first, stride, seed = rank, world, SEED_TABLE        # local j <- global j * world + rank of ONE table
+    else:
+        first, stride, seed = 0, 1, SEED_TABLE + rank        # an own table per rank
+    t, table, out = fold_leg(env, zk, n, seed, first, stride, r, args.steps, args.warmup)
+    dt, kern_ms = t["dt"], t["kernel_ms"]
     muls = half * args.steps * world
-    value = muls / dt
     algo_bytes = 96.0 * half                               # per launch: 2 x 32 B read + 32 B write per mul
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    per = f"2^{args.log_n}-entry table per GPU" if not strong else f"ONE 2^{args.log_n}-entry table, 2^{args.log_n}/{world} entries per GPU"
+    if world == 1:
+        per = f"2^{args.log_n}-entry table on one GPU"
+    elif strong:
+        per = f"ONE 2^{args.log_n}-entry table low-bit-sharded {world}-way (config 5), 2^{args.log_n}/{world} entries per GPU"
+    else:
+        per = f"a 2^{args.log_n}-entry table per GPU"
     result = {
-        "metric": f"field-mul/s (2^{args.log_n} MLE fold)", "value": value, "unit": "field-mul/s", "n_gpus": world,
+        "metric": f"field-mul/s (2^{args.log_n} MLE fold)", "value": muls / dt, "unit": "field-mul/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": f"{args.log_n}-variable MLE fold (partial_evaluate var 0), BLS12-381 Fr, {per}",
-                   "log_n": args.log_n, "field": "bls12_381_fr",
+                   "log_n": args.log_n, "field": "bls12_381_fr", "entries_per_gpu": n,
                    "arithmetic": "255-bit Montgomery field, 8 x u32 limbs in HBM, products as 29-bit-limb v_mad_u64_u32 scans",
-                   "sharding": "low-bit shard per rank, no data-path collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "kernel": "fold0_kernel<Fr381>", "kernel_ms": kern_ms, "kernel_ms_median": kern_ms_median,
-                     "achieved_median": algo_bytes / (kern_ms_median * 1e-3) / 1e9, "timing_chunks": len(per_chunk),
-                     "algorithmic_bytes_per_launch": algo_bytes},
-        "collectives": collectives,
+                   "sharding": "low-bit shard per rank, no data-path collective in the fold; the sharded proof and MSM of the same table are under config5_strong"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": "fold0_kernel<Fr381>", "kernel_ms": kern_ms, "kernel_ms_median": t["kernel_ms_median"],
+                     "achieved_median": algo_bytes / (t["kernel_ms_median"] * 1e-3) / 1e9, "timing_chunks": t["chunks"],
+                     "algorithmic_bytes_per_launch": algo_bytes, "per": "GPU (rank 0's launches)"},
+        "collectives": env.collectives,
     }
-    for rnd in ("r2", "r1"):                                 # PMC passes are separate rocprofv3 runs (committed summary)
+    failed = []
+    for rnd in ("r3", "r2", "r1"):                           # PMC passes are separate rocprofv3 runs (committed summary)
         pmc = os.path.join(ROOT, "profiles", rnd, "fold_2p24_pmc.json")
-        if args.log_n == 24 and not strong and os.path.exists(pmc):
+        if n == 1 << 24 and os.path.exists(pmc):
             with open(pmc) as f:
                 result["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
             result["roofline"]["traffic_source"] = (f"profiles/{rnd}/fold_2p24_pmc.json (committed summary of separate rocprofv3 --pmc FETCH_SIZE / "
                                                     "WRITE_SIZE passes, FETCH doubled per the gfx950 note; not re-measured in this run)")
             break
+    if rank == 0 and not args.no_cpu_baseline:
+        # what was timed is a correct fold: sampled outputs of the last launch against the oracle on the host mirror of the inputs
+        result["post_check"] = post_check_fold(zk, field, out, r, seed, first, stride, half)
+    del table, out
+    if world > 1 and strong and not args.no_weak:            # secondary: the weak-scaling form (a 2^log-n table per GPU)
+        wt, wtab, wout = fold_leg(env, zk, n_global, SEED_TABLE + rank, 0, 1, r, min(args.steps, 300), min(args.warmup, 20), prewarm_s=0.0)
+        wb = 96.0 * (n_global // 2) / (wt["kernel_ms"] * 1e-3) / 1e9
+        result["weak"] = {"what": f"a 2^{args.log_n}-entry table per GPU, no data-path collective (linear by construction)",
+                          "value": (n_global // 2) * min(args.steps, 300) * world / wt["dt"], "unit": "field-mul/s", "steps": min(args.steps, 300),
+                          "kernel_ms": wt["kernel_ms"], "hbm_GBps_per_gpu": wb, "frac_per_gpu": wb / HBM_PEAK_GBPS}
+        del wtab, wout
     if world > 1:
-        try:                                               # a failure in a secondary leg must not cost the headline line
-            result["sharded_sumcheck"] = sharded_gkr_sumcheck_leg(zk, comm, rank, world, collectives)
+        try:
+            result["sharded_sumcheck"] = sharded_gkr_sumcheck_leg(zk, env)
         except Exception as e:                             # noqa: BLE001
             result["sharded_sumcheck"] = {"error": repr(e)}
+            failed.append("sharded_sumcheck")
+    msm_shared = None
     if not args.no_config5:
         try:
-            result["config5_strong"] = config5_leg(zk, comm, args, rank, world, collectives)
+            result["config5_strong"], msm_shared = config5_leg(zk, env, args)
         except Exception as e:                             # noqa: BLE001
             if world == 1:
                 raise
             result["config5_strong"] = {"error": repr(e)}
+            failed.append("config5_strong")
     if not args.no_msm:
         try:
-            result["msm"] = msm_leg(zk, comm, args, rank, world)
+            result["msm"] = msm_leg(zk, env, args, msm_shared)
             if rank == 0 and not args.no_cpu_baseline:
                 result["msm"]["cpu_baseline"] = cpu_baseline_msm(zk)
         except Exception as e:                             # noqa: BLE001
             if world == 1:
                 raise
             result["msm"] = {"error": repr(e)}
+            failed.append("msm")
+    if world == 1 and not args.no_configs:
+        result["configs"] = baseline_configs(zk, args)
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(zk, field)
-        # what was timed is a correct fold: sampled outputs of the last launch against the oracle on the host mirror of the inputs
-        result["post_check"] = post_check_fold(zk, field, out, r, seed, first, stride, half)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    comm.close()
-    if world > 1:
-        dist.destroy_process_group()
+    if failed:
+        result["failed_legs"] = failed
+    return result
 
 
-def _barrier_time(world, fn, reps, rehearse):
-    """max over ranks of the mean wall time of `fn` over `reps` calls between barriers"""
-    import torch
-    import torch.distributed as dist
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = [fn() for _ in range(reps)]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = (time.perf_counter() - t0) / reps
-    if world > 1:                                          # the default group's backend decides where its tensors live
-        tt = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    return dt, outs[-1]
+# ---- checks of what was timed ---------------------------------------------------------------------------------------------
+def verifier_equations_basic(zk, claimed, rp, ch):
+    """verifier.rs:47-64 on a basic-sumcheck proof: every round's two half sums add up to the running claim; -> (ok, last claim)"""
+    import numpy as np
+    from zkmle_amd import _lib
+    S = zk.sharded
+    S._declare_host()
+    Lb = zk.lib()
+    cur, ok = claimed, True
+    for k in range(rp.shape[0]):
+        ok = ok and np.array_equal(S.fe_add(0, rp[k, 0], rp[k, 1]), cur)
+        d = np.zeros(4, np.uint64)
+        _lib.check(Lb.zk_fe_sub(0, _lib.p64(rp[k, 1]), _lib.p64(rp[k, 0]), _lib.p64(d)))
+        m = np.zeros(4, np.uint64)
+        _lib.check(Lb.zk_fe_mul(0, _lib.p64(np.ascontiguousarray(ch[k])), _lib.p64(d), _lib.p64(m)))
+        cur = S.fe_add(0, rp[k, 0], m)
+    return bool(ok), cur
 
 
-def config5_leg(zk, comm, args, rank, world, collectives):
+def msm_identity_check(zk, scalars, a_int, d_int, got):
+    """The bases are P_i = [a + i d] G, so MSM = [a sum s_i + d sum i s_i] G: two exact integer sums over the canonical scalars
+    (16-bit pieces, vectorised) and ONE scalar multiplication by the checker (oracle) -- O(N), independent of the bucket method."""
+    import numpy as np
+    from oracle import oracle as O
+    from zkmle_amd import _lib as L
+    mont = scalars.evaluated_values
+    n = mont.shape[0]
+    canon = np.zeros_like(mont)
+    L.check(L.lib().zk_vec_to_canonical(0, L.p64(mont), n, L.p64(canon)))
+    idx = np.arange(n, dtype=np.uint64)
+    s_sum, is_sum = 0, 0
+    step = 1 << 20
+    for k in range(4):
+        for j in range(4):
+            piece = (canon[:, k] >> np.uint64(16 * j)) & np.uint64(0xFFFF)
+            shift = 64 * k + 16 * j
+            s_sum += int(piece.sum(dtype=np.uint64)) << shift
+            acc = 0
+            for lo in range(0, n, step):                                        # 2^20 terms below 2^40 each: < 2^60
+                acc += int((idx[lo:lo + step] * piece[lo:lo + step]).sum(dtype=np.uint64))
+            is_sum += acc << shift
+    R = O.modulus(O.FR381)
+    k = (a_int * s_sum + d_int * is_sum) % R
+    want = O.g1_mul_fr(O.g1_generator(), O.from_ints(O.FR381, [k])[0])
+    return bool(np.array_equal(np.asarray(got, np.uint64).reshape(-1), np.asarray(want, np.uint64).reshape(-1)))
+
+
+# ---- config 5 -----------------------------------------------------------------------------------------------------------------
+def config5_leg(zk, env, args):
     """BASELINE config 5 at this rank count (strong scaling): the 2^log-n table low-bit-sharded over the ranks through the
     sharded sumcheck prover (include/zkmle.h zk_sharded_sumcheck_basic_prove, whole-table absorb off) and the 2^log-n-term MSM
-    slice-sharded (zk_sharded_msm_g1)."""
+    slice-sharded (zk_sharded_msm_g1).  Both are checked after the timing."""
     import numpy as np
     from zkmle_amd import _lib
     S = zk.sharded
     Lb = zk.lib()
-    field = 0
+    comm, rank, world = env.comm, env.rank, env.world
     n_global = 1 << args.log_n
     n = n_global // world
-    out = {"what": f"one 2^{args.log_n}-entry Fr table and one 2^{args.log_n}-term MSM sharded {world}-way", "backend": collectives["backend"],
-           "library_comm": collectives["library"]}
+    out = {"what": f"one 2^{args.log_n}-entry Fr table and one 2^{args.log_n}-term MSM sharded {world}-way", "backend": env.collectives["backend"],
+           "library_comm": env.collectives["library"]}
     # -- sumcheck prover rounds on the sharded table
-    table = zk.MultilinearPolynomial.alloc(field, n)
+    table = zk.MultilinearPolynomial.alloc(0, n)
     _lib.check(Lb.zk_table_fill_random_strided(table._h, SEED_TABLE, rank, world))
     shard = S.GpuShard(table)
     S.sumcheck_basic_prove_device(comm, shard, absorb_table=False)            # warm-up
     rx0, nc0 = comm.native_stats()
-    dt, (claimed, rp, ch) = _barrier_time(world, lambda: S.sumcheck_basic_prove_device(comm, shard, absorb_table=False), 5, args.rehearse)
+    dt, (claimed, rp, ch) = env.timed(lambda: S.sumcheck_basic_prove_device(comm, shard, absorb_table=False), 5)
     rx1, nc1 = comm.native_stats()
     # verifier equations (verifier.rs:47-70) on the proof just timed: claim chain + the table evaluated at the challenges
-    cur, ok = claimed, True
-    for k in range(rp.shape[0]):
-        ok = ok and np.array_equal(S.fe_add(field, rp[k, 0], rp[k, 1]), cur)
-        d = np.zeros(4, np.uint64)
-        _lib.check(Lb.zk_fe_sub(field, _lib.p64(rp[k, 1]), _lib.p64(rp[k, 0]), _lib.p64(d)))
-        m = np.zeros(4, np.uint64)
-        _lib.check(Lb.zk_fe_mul(field, _lib.p64(np.ascontiguousarray(ch[k])), _lib.p64(d), _lib.p64(m)))
-        cur = S.fe_add(field, rp[k, 0], m)
+    ok, cur = verifier_equations_basic(zk, claimed, rp, ch)
     ok = ok and np.array_equal(S.mle_evaluate(comm, table, ch), cur)
+    # unavoidable HBM bytes of the round phase: the segment sums read the table once (32 B / entry); pass k of <= 4 rounds reads
+    # 16^-k of it again and writes 1/16 of what it read: 32 n (1 + 17/16 (1 + 1/16 + ...)) = 32 n (1 + 17/15)
+    traffic = 32.0 * n_global * (1 + 17.0 / 15.0)
     out["sumcheck"] = {"what": f"Prover::prove rounds of the 2^{args.log_n} table ({rp.shape[0]} rounds), 2^{args.log_n}/{world} entries per rank, "
                                "up to 4 rounds per pass over the shard: one all-reduce(SUM) of 2^m x 9 int64 words (m <= 4 rounds' segment sums) on the prover's stream per pass, replicated one-launch tail, transcript steps on each rank's host through the mailbox",
                        "ms_per_proof": dt * 1e3, "field_mul_per_s": (n_global - 1) / dt, "rounds": int(rp.shape[0]),
                        "collectives_per_proof": (nc1 - nc0) // 5, "bytes_received_per_proof": (rx1 - rx0) // 5,
+                       "hbm_GBps_whole_proof": traffic / dt / 1e9, "frac_of_hbm_peak_whole_proof": traffic / dt / 1e9 / (HBM_PEAK_GBPS * world),
                        "verifier_equations_hold": bool(ok)}
+    if not ok:
+        raise RuntimeError("config 5: the timed sharded proof fails the verifier's equations")
     del shard, table
     # -- MSM, terms sliced over the ranks: rank g owns the terms [g n / G, (g + 1) n / G)
     lo = rank * n
     a = zk.from_ints(0, [SEED_MSM])[0]
     d = zk.from_ints(0, [MSM_D])[0]
-    a_lo = np.zeros(4, np.uint64)
-    lo_fe = zk.from_ints(0, [lo])[0]
-    _lib.check(Lb.zk_fe_mul(0, _lib.p64(lo_fe), _lib.p64(d), _lib.p64(a_lo)))
-    a_lo = S.fe_add(0, a, a_lo)                                               # P_i = [a + i d] G for the global index i
+    a_lo = zk.from_ints(0, [SEED_MSM + lo * MSM_D])[0]                        # P_i = [a + i d] G for the global index i
     bases = zk.G1Bases.synthetic(n, a_lo, d)
     scalars = zk.MultilinearPolynomial.alloc(0, n)
     _lib.check(Lb.zk_table_fill_random_strided(scalars._h, SEED_MSM, lo, 1))
     S.msm_device(comm, scalars, bases, 0, True)                               # warm-up
-    dt, (pt, st) = _barrier_time(world, lambda: S.msm_device(comm, scalars, bases, 0, True), args.msm_reps, args.rehearse)
+    dt, (pt, st) = env.timed(lambda: S.msm_device(comm, scalars, bases, 0, True), args.msm_reps)
     same = np.array_equal(comm.all_gather(pt), np.broadcast_to(pt, (world, 12)))
     W = st["windows"]
     out["msm"] = {"what": f"2^{args.log_n}-term MSM, 2^{args.log_n}/{world} terms per rank, one all-gather of {world} affine points + {world - 1} additions",
                   "ms_per_msm": dt * 1e3, "g1_add_per_s": W * n_global / dt, "terms_per_s": n_global / dt, "window_bits": st["window_bits"],
                   "windows": W, "local_device_ms": st["ms_total"], "same_point_on_every_rank": bool(same),
                   "point_x_limb0": int(pt[0])}
-    return out
+    if rank == 0:                                                             # the O(N) identity on ALL the scalars of the global MSM
+        if world > 1:
+            full = zk.MultilinearPolynomial.alloc(0, n_global)
+            _lib.check(Lb.zk_table_fill_random_strided(full._h, SEED_MSM, 0, 1))
+        else:
+            full = scalars
+        t0 = time.perf_counter()
+        good = msm_identity_check(zk, full, SEED_MSM, MSM_D, pt)
+        out["msm"]["post_check"] = {"identity": "MSM == [a sum s_i + d sum i s_i] G for bases [a + i d] G", "holds": good,
+                                    "check_s": time.perf_counter() - t0}
+        if not good:
+            raise RuntimeError("config 5: the timed MSM's point fails the linear identity of its bases")
+    shared = {"scalars": scalars, "bases": bases, "dt": dt, "pt": pt, "st": st, "check": out["msm"].get("post_check")} if world == 1 else None
+    return out, shared
 
 
-def sharded_gkr_sumcheck_leg(zk, comm, rank, world, collectives, log_local=20):
+def sharded_gkr_sumcheck_leg(zk, env, log_local=20):
     """A whole GKR sumcheck (4 tables, degree 2; sumcheck_gkr_protocol.rs:24-67) sharded over the ranks, weak: 2^20 entries per
     table per rank.  One C-ABI call per proof (zk_sharded_sumcheck_gkr_prove)."""
     import numpy as np
     S = zk.sharded
+    rank, world, comm = env.rank, env.world, env.comm
     n = 1 << log_local
     MP = zk.MultilinearPolynomial
     tabs = [[MP.random(0, n, 0x5EED0400 + 16 * rank + 2 * p + f) for f in range(2)] for p in range(2)]
     shard = S.GpuSumShard(0, tabs)
     claimed = np.zeros(4, np.uint64)
     S.sumcheck_gkr_prove_device(comm, shard, claimed, zk.Transcript())      # warm-up
-    dt, (co, ch, fin) = _barrier_time(world, lambda: S.sumcheck_gkr_prove_device(comm, shard, claimed, zk.Transcript()), 3,
-                                      collectives["backend"].startswith("gloo"))
+    dt, (co, ch, fin) = env.timed(lambda: S.sumcheck_gkr_prove_device(comm, shard, claimed, zk.Transcript()), 3)
     rounds = int(co.shape[0])
     return {"what": f"GKR sumcheck on 4 tables of 2^{log_local} entries per rank ({rounds} rounds over {world} ranks), "
                     "one all-reduce(SUM) of 27 int64 words per large round", "ms_per_proof": dt * 1e3, "rounds": rounds,
-            "ms_per_round": dt * 1e3 / rounds, "field_mul_per_s": 5.0 * 2 * n * world / dt, "backend": collectives["backend"]}
+            "ms_per_round": dt * 1e3 / rounds, "field_mul_per_s": 5.0 * 2 * n * world / dt, "backend": env.collectives["backend"]}
 
 
-def msm_leg(zk, comm, args, rank, world):
-    """G1-add/s on the 2^log-n Pippenger MSM (BASELINE.json's second metric), weak: one 2^log-n-term MSM per rank, then one
-    all-gather of `world` affine points + world-1 additions (no bandwidth-sized collective)."""
-    import numpy as np
+# ---- MSM ------------------------------------------------------------------------------------------------------------------------
+def msm_leg(zk, env, args, shared=None):
+    """G1-add/s on the 2^log-n Pippenger MSM (BASELINE.json's second metric): one 2^log-n-term MSM per rank, then one
+    all-gather of `world` affine points + world-1 additions (no bandwidth-sized collective).  At N = 1 this IS config 5's MSM
+    (same scalars, same bases): it is run and checked once and reported under both keys."""
+    rank, world, comm = env.rank, env.world, env.comm
     n = 1 << args.log_n
-    a = zk.from_ints(0, [SEED_MSM + rank])[0]
-    d = zk.from_ints(0, [MSM_D])[0]
-    bases = zk.G1Bases.synthetic(n, a, d)                   # P_i = [a + i d] G, generated on the device
-    scalars = zk.MultilinearPolynomial.random(0, n, SEED_MSM + 97 * rank)
     S = zk.sharded
-    S.msm_device(comm, scalars, bases, 0, True)             # warm-up
-    dt, (pt, st) = _barrier_time(world, lambda: S.msm_device(comm, scalars, bases, 0, True), args.msm_reps, args.rehearse)
+    if shared is not None:
+        dt, pt, st, check = shared["dt"], shared["pt"], shared["st"], shared["check"]
+    else:
+        a = zk.from_ints(0, [SEED_MSM + rank])[0]
+        d = zk.from_ints(0, [MSM_D])[0]
+        bases = zk.G1Bases.synthetic(n, a, d)                   # P_i = [a + i d] G, generated on the device
+        scalars = zk.MultilinearPolynomial.random(0, n, SEED_MSM + 97 * rank)
+        S.msm_device(comm, scalars, bases, 0, True)             # warm-up
+        dt, (pt, st) = env.timed(lambda: S.msm_device(comm, scalars, bases, 0, True), args.msm_reps)
+        check = None
+        if world == 1:
+            t0 = time.perf_counter()
+            good = msm_identity_check(zk, scalars, SEED_MSM, MSM_D, pt)
+            check = {"identity": "MSM == [a sum s_i + d sum i s_i] G for bases [a + i d] G", "holds": good, "check_s": time.perf_counter() - t0}
+            if not good:
+                raise RuntimeError("the timed MSM's point fails the linear identity of its bases")
     W = st["windows"]
     res = {"metric": f"G1-add/s (2^{args.log_n} MSM)", "value": W * n * world / dt, "unit": "G1-add/s",
            "terms_per_s": n * world / dt, "ms_per_msm": dt * 1e3, "window_bits": st["window_bits"], "windows": W,
            "adds_per_term": W, "device_ms": {k: st[k] for k in ("ms_digits", "ms_sort", "ms_buckets", "ms_reduce", "ms_total")},
            "unique_bytes_per_term": 128, "hbm_GBps_unique": 128.0 * n / (st["ms_total"] * 1e-3) / 1e9,
            "workload": f"2^{args.log_n} random Fr scalars x synthetic affine bases [a + i d]G per GPU; one Pippenger per rank, all-gather of {world} points"}
+    if check is not None:
+        res["post_check"] = check
     try:
         res["roofline"] = msm_roofline(st)
     except Exception as e:                                  # noqa: BLE001
@@ -419,6 +610,135 @@ def measured_mad_peak():
     return 3.13e13, "profiles/r1/microbench_instr_rates.jsonl (committed; the in-run micro-benchmark was unavailable)"
 
 
+# ---- BASELINE configs 2, 3, 4 (one GPU) -------------------------------------------------------------------------------------------
+def event_time_ms(fn, reps, warm=3):
+    """mean HIP-event time of `fn` (enqueue-only work on the current stream) over `reps` back-to-back calls"""
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def baseline_configs(zk, args):
+    """BASELINE.json configs 2, 3 and 4 on this GPU, each timed and then checked (proofs through the verifier, the MSM through the
+    identity of its bases).  A failed check aborts the run: no line."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from zkmle_amd import _lib
+    L = zk.lib()
+    MP = zk.MultilinearPolynomial
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {}
+    # -- config 2: 20-variable sumcheck fold + the whole Prover::prove (prover.rs:35-71)
+    n = 1 << 20
+    poly = MP.random(0, n, 0x5EED0002)
+    dst = MP.alloc(0, n // 2)
+    r = np.zeros(4, np.uint64)
+    _lib.check(L.zk_host_fill_random(0, SEED_TABLE, 77, 1, _lib.p64(r)))
+    fold_ms = event_time_ms(lambda: _lib.check(L.zk_mle_fold(poly._h, 0, _lib.p64(r), dst._h, stream)), 2000, warm=200)
+    prover = zk.Prover.init(0, poly)
+    prover.prove()
+    t0 = time.perf_counter()
+    proof = prover.prove()
+    prove_s = time.perf_counter() - t0
+    st = zk.sumcheck.last_stats()
+    verified = zk.Verifier.init().verify(proof)
+    if not verified:
+        raise SystemExit("bench.py: config 2's proof is rejected by the verifier")
+    gb = 96.0 * (n // 2) / (fold_ms * 1e-3) / 1e9
+    out["cfg2"] = {"what": "20-variable MLE sumcheck fold, BLS12-381 Fr, 1xMI355X", "fold_us": fold_ms * 1e3, "fold_field_mul_per_s": (n // 2) / (fold_ms * 1e-3),
+                   "fold_GBps": gb, "fold_frac": gb / HBM_PEAK_GBPS, "fold_note": "the 2^20 table (32 MiB in + 16 MiB out) fits the 256 MiB MALL: above-HBM rates are cache hits",
+                   "prove_ms": prove_s * 1e3, "rounds_ms": st["ms_rounds"], "absorb_ms": st["ms_absorb"],
+                   "rounds_field_mul_per_s": (n - 1) / (st["ms_rounds"] * 1e-3), "post_check": {"verifier_accepts": bool(verified)}}
+    del poly, dst, prover, proof
+    # -- config 3: multilinear_kzg::commit, 2^20-scalar Pippenger MSM (multilinear_kzg.rs:25-45)
+    bases = zk.G1Bases.synthetic(n, zk.from_ints(0, [SEED_MSM])[0], zk.from_ints(0, [MSM_D])[0])
+    scalars = MP.random(0, n, SEED_MSM + 3)
+    zk.kzg.msm(scalars, bases, 0, True)
+    best = None
+    for _ in range(5):
+        t0 = time.perf_counter()
+        pt, ms = zk.kzg.msm(scalars, bases, 0, True)
+        wall = time.perf_counter() - t0
+        if best is None or wall < best[0]:
+            best = (wall, ms)
+    wall, ms = best
+    good = msm_identity_check(zk, scalars, SEED_MSM, MSM_D, pt)
+    if not good:
+        raise SystemExit("bench.py: config 3's MSM fails the linear identity of its bases")
+    out["cfg3"] = {"what": "multilinear_kzg::commit 2^20-scalar Pippenger MSM, BLS12-381 G1, 1xMI355X", "ms_per_msm": wall * 1e3,
+                   "device_ms": {k: ms[k] for k in ("ms_digits", "ms_sort", "ms_buckets", "ms_reduce", "ms_total")},
+                   "terms_per_s": n / wall, "g1_add_per_s": ms["windows"] * n / wall, "window_bits": ms["window_bits"], "windows": ms["windows"],
+                   "post_check": {"identity_holds": bool(good)}}
+    del bases, scalars
+    # -- config 4: GKR prover, depth 3, 2^22 gates per layer (gkr_protocol.rs:57-143 on gate lists)
+    lg, depth = 22, 3
+    ng = 1 << lg
+    rng = np.random.default_rng(0x5EED0004)
+    rows = []
+    for _ in range(depth):
+        g = np.zeros((ng, 4), np.uint64)
+        g[:, 0] = rng.integers(0, ng, ng)
+        g[:, 1] = rng.integers(0, ng, ng)
+        g[:, 2] = np.arange(ng)
+        g[:, 3] = rng.integers(0, 2, ng)
+        rows.append(g)
+    x = MP.random(0, ng, 0x5EED0004).evaluated_values
+    t0 = time.perf_counter()
+    circuit = zk.gkr.SparseCircuit(rows, [lg] * depth, ng)
+    compile_s = time.perf_counter() - t0
+    zk.gkr.sparse_prove(0, None, None, x, circuit=circuit)
+    t0 = time.perf_counter()
+    proof = zk.gkr.sparse_prove(0, None, None, x, circuit=circuit)
+    prove_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ok = zk.gkr.sparse_verify(0, rows, [lg] * depth, proof, x)
+    verify_s = time.perf_counter() - t0
+    if not ok:
+        raise SystemExit("bench.py: config 4's proof is rejected by the sparse verifier")
+    del circuit, rows
+    # the two round kernels of sumcheck_gkr_protocol.rs:113-143 alone, on 4 tables of 2^22 (2 products x 2 factors): enqueue-only calls
+    S = zk.sharded
+    lib = S._declare_host()
+    sc = zk.sumcheck._decl()
+    tabs = [MP.random(0, ng, 0x5EED0440 + k) for k in range(4)]
+    outs = [MP.alloc(0, ng // 2) for _ in range(4)]
+    ta = (C.c_void_p * 4)(*[t._h for t in tabs])
+    oa = (C.c_void_p * 4)(*[t._h for t in outs])
+
+    def fold_round():
+        _lib.check(lib.zk_sumpoly_fold_round_evals(ta, oa, 2, 2, _lib.p64(r), None))
+
+    fre_ms = event_time_ms(fold_round, 200, warm=20)
+    re_ms = event_time_ms(lambda: _lib.check(sc.zk_sumpoly_round_evals(ta, 2, 2, None)), 200, warm=20)
+    q = ng // 4
+    fre_bytes = 4 * (ng + ng // 2) * 32.0
+    re_bytes = 4 * ng * 32.0
+    out["cfg4"] = {"what": "GKR prover, depth-3 layered circuit, 2^22 gates/layer (random wiring), BLS12-381 Fr, 1xMI355X; sparse (linear-time) prover",
+                   "circuit_compile_s": compile_s, "prove_s": prove_s, "device_ms_per_layer": [float(v) for v in proof.ms_layers], "verify_s": verify_s,
+                   "gates_per_s": depth * ng / prove_s,
+                   "round_kernels": {
+                       "what": "4 tables of 2^22 entries (2 products x 2 factors), HIP events over 200 back-to-back enqueue-only launches",
+                       "fold_round_evals_kernel": {"us": fre_ms * 1e3, "GBps": fre_bytes / (fre_ms * 1e-3) / 1e9, "frac": fre_bytes / (fre_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                   "algorithmic_bytes": fre_bytes, "field_mul_per_s": 12.0 * q / (fre_ms * 1e-3),
+                                                   "field_mul_per_pair_index": "8 fold products + 4 evaluation products (the point 1 is derived)"},
+                       "round_evals_kernel": {"us": re_ms * 1e3, "GBps": re_bytes / (re_ms * 1e-3) / 1e9, "frac": re_bytes / (re_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                              "algorithmic_bytes": re_bytes, "field_mul_per_s": 6.0 * (ng // 2) / (re_ms * 1e-3),
+                                              "field_mul_per_pair_index": "6 evaluation products (points 0, 1, 2 of 2 products)"}},
+                   "post_check": {"sparse_verifier_accepts": bool(ok)},
+                   "note": "prove_s includes the sequential host Keccak absorb of the 2^22-entry output layer; circuit_compile_s is paid once per circuit"}
+    return out
+
+
+# ---- CPU baselines (the oracle, timed on this host; reported, not the target) ------------------------------------------------------
 def cpu_baseline_msm(zk):
     """the oracle's restatement of the reference's NAIVE commit (one 255-bit double-and-add per term,
     multilinear_kzg.rs:37-42) on 2^10 terms, one host core; the reference has no MSM routine.  Beside it, a CPU Pippenger

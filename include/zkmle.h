@@ -175,7 +175,9 @@ int zk_sumpoly_reduce(const zk_table *const *tables, size_t nprod, size_t nfac, 
 /* ProductPolynomial::multiply_polynomials_element_wise (product_polynomial.rs:58-73): out[i] = prod_f tables[f][i]; nfac >= 2
  * (the reference asserts "more than one polynomial required for mul operation") */
 int zk_prodpoly_reduce(const zk_table *const *tables, size_t nfac, zk_table *out);
-/* generate_round_univariate sumcheck_gkr_protocol.rs:113-143 ; out: nfac+1 evaluations at 0..nfac */
+/* generate_round_univariate sumcheck_gkr_protocol.rs:113-143 ; out: nfac+1 evaluations at 0..nfac.
+ * out == NULL (here and in zk_sumpoly_fold_round_evals' out_evals): the pass over the tables is only ENQUEUED on the current
+ * stream -- no reduction of the per-workgroup partials, no read-back -- which is how bench.py times the round kernels alone. */
 int zk_sumpoly_round_evals(const zk_table *const *tables, size_t nprod, size_t nfac, uint64_t *out);
 /* one fused prover round on caller-managed tables: fold every table of `in` by `value` into `out`
  * (len/2 each) and return the NEXT round's nfac+1 evaluations of the folded tables (len >= 4).
@@ -419,10 +421,20 @@ typedef struct {
 int zk_comm_unique_id(uint8_t out128[128]);                       /* ncclGetUniqueId */
 int zk_comm_init_rccl(const uint8_t id128[128], int nranks, int rank, zk_comm **out);
 int zk_comm_from_host_ops(const zk_comm_host_ops *ops, int nranks, int rank, zk_comm **out);
+/* The ranks as THREADS of one process (one thread per GPU, or several ranks sharing one GPU in tests and rehearsals): a
+ * group of `nranks` ends that exchange through the process's own host memory.  Every rank's thread creates its end with
+ * zk_comm_from_local_group (backend "local-threads") and calls the provers concurrently, each on its own stream; the group
+ * outlives its ends and is freed by the caller after them.  zk_comm_local_group_abort wakes every rank that waits in an
+ * exchange (they return ZK_E_COMM): what a rank calls when its own proof failed, so that nobody hangs. */
+typedef struct zk_comm_local_group zk_comm_local_group;
+int zk_comm_local_group_new(int nranks, zk_comm_local_group **out);
+int zk_comm_local_group_free(zk_comm_local_group *g);
+int zk_comm_local_group_abort(zk_comm_local_group *g);
+int zk_comm_from_local_group(zk_comm_local_group *g, int rank, zk_comm **out);
 int zk_comm_free(zk_comm *c);
 int zk_comm_rank(const zk_comm *c);
 int zk_comm_size(const zk_comm *c);
-const char *zk_comm_backend(const zk_comm *c);                    /* "rccl" or "host-ops" */
+const char *zk_comm_backend(const zk_comm *c);                    /* "rccl", "host-ops" or "local-threads" */
 /* payload bytes this rank has received through the communicator so far (all-reduce: the buffer; all-gather / gather at the
  * root: the other ranks' parts; broadcast: the buffer on non-root ranks) and the number of collectives issued */
 int zk_comm_stats(const zk_comm *c, uint64_t *bytes_received, uint64_t *collectives);
@@ -430,6 +442,10 @@ int zk_comm_stats(const zk_comm *c, uint64_t *bytes_received, uint64_t *collecti
 int zk_comm_all_reduce_sum_i64(zk_comm *c, void *dev_buf, size_t count);
 int zk_comm_all_gather(zk_comm *c, const void *dev_send, void *dev_recv, size_t bytes);
 int zk_comm_broadcast(zk_comm *c, void *dev_buf, size_t bytes, int root);
+/* the same exchanges on HOST buffers, for the callback kinds only ("host-ops", "local-threads"; ZK_E_ARG on an RCCL
+ * communicator): op 0 = all-reduce(SUM) of n int64 words in place, 1 = all-gather of n bytes per rank into host_recv,
+ * 2 = gather to `root` (host_recv on the root only), 3 = broadcast of n bytes from `root`.  Needs no device. */
+int zk_comm_host_exchange(zk_comm *c, int op, void *host_buf, void *host_recv, size_t n, int root);
 
 /* Prover::prove (prover.rs:35-71) of the global table whose low-bit shard is `shard` (local length 2^m, global 2^(m+k)).
  * Same proof bytes on every rank as zk_sumcheck_basic_prove on the interleaved table.  Per local round: one fused kernel,

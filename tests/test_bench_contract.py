@@ -39,7 +39,7 @@ def last_json(stdout):
 
 @pytest.mark.gpu
 def test_one_gpu_line_has_the_contract_keys():
-    p = run(["--steps", "5", "--warmup", "2", "--log-n", "16", "--msm-reps", "1"])
+    p = run(["--steps", "5", "--warmup", "2", "--log-n", "16", "--msm-reps", "1", "--no-configs"])
     assert p.returncode == 0, p.stderr[-2000:]
     d = last_json(p.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
@@ -53,17 +53,22 @@ def test_one_gpu_line_has_the_contract_keys():
     assert d["post_check"]["bit_exact_vs_oracle"] is True
     m = d["msm"]
     assert m["roofline"]["bound"].startswith("valu") and 0 < m["roofline"]["frac"] < 1.2 and m["cpu_baseline"]["all_cores"]["cores"] >= 1
+    assert m["post_check"]["holds"] is True and m["terms_per_s"] > 0 and m["window_bits"] >= 1
     c5 = d["config5_strong"]
     assert c5["sumcheck"]["verifier_equations_hold"] is True and c5["msm"]["same_point_on_every_rank"] is True
+    assert c5["msm"]["post_check"]["holds"] is True
 
 
 @pytest.mark.gpu
-def test_self_launch_two_ranks_rehearsal():
-    # `--gpus 2` with no WORLD_SIZE: the launcher starts the two ranks itself (both on cuda:0 over gloo with --rehearse)
-    p = run(["--gpus", "2", "--rehearse", "--steps", "4", "--warmup", "1", "--log-n", "14", "--msm-reps", "1", "--no-cpu-baseline"])
+def test_eight_rank_rehearsal_is_strong_scaling_of_one_table():
+    # BASELINE config 5's split on one GPU: 8 ranks as threads of the bench process (a one-GPU box allows 6 processes on its card)
+    p = run(["--gpus", "8", "--rehearse", "--steps", "4", "--warmup", "1", "--log-n", "16", "--msm-reps", "1", "--no-cpu-baseline"])
     assert p.returncode == 0, p.stderr[-2000:]
     d = last_json(p.stdout)
-    assert d["n_gpus"] == 2 and d["collectives"]["library"] == "host-ops" and "rehearsal" in d["collectives"]["backend"]
-    assert d["config5_strong"]["sumcheck"]["verifier_equations_hold"] is True
-    assert d["config5_strong"]["msm"]["same_point_on_every_rank"] is True
-    assert "ms_per_proof" in d["sharded_sumcheck"]
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["entries_per_gpu"] == (1 << 16) // 8
+    assert d["collectives"]["library"] == "local-threads" and "rehearsal" in d["collectives"]["backend"]
+    assert "failed_legs" not in d
+    c5 = d["config5_strong"]
+    assert c5["sumcheck"]["verifier_equations_hold"] is True and c5["sumcheck"]["rounds"] == 16
+    assert c5["msm"]["same_point_on_every_rank"] is True and c5["msm"]["post_check"]["holds"] is True
+    assert "ms_per_proof" in d["sharded_sumcheck"] and d["weak"]["value"] > 0

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -119,13 +120,84 @@ struct TableSet {     // pooled temporaries, freed with the set
 
 }  // namespace
 
+// The ranks as threads of one process: a generation barrier and one published pointer per rank.  Every exchange is
+// publish -> barrier -> read the other ranks' host buffers -> barrier (nobody reuses a buffer another rank still reads).
+struct zk_comm_local_group {
+    int nranks;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool aborted = false;
+    std::vector<const void *> ptr;
+    explicit zk_comm_local_group(int n) : nranks(n), ptr((size_t)n, nullptr) {}
+    int barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return 1;
+        const uint64_t gen = generation;
+        if (++arrived == nranks) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+            return 0;
+        }
+        cv.wait(lk, [&] { return generation != gen || aborted; });
+        return generation != gen ? 0 : 1;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
+    }
+};
+
+namespace {
+struct LocalEnd { zk_comm_local_group *g; int rank; };
+int local_all_reduce(void *ctx, int64_t *buf, size_t count) {
+    LocalEnd *e = (LocalEnd *)ctx;
+    e->g->ptr[(size_t)e->rank] = buf;
+    if (e->g->barrier()) return 1;
+    std::vector<int64_t> acc(count, 0);
+    for (int r = 0; r < e->g->nranks; r++) {
+        const int64_t *src = (const int64_t *)e->g->ptr[(size_t)r];
+        for (size_t i = 0; i < count; i++) acc[i] += src[i];
+    }
+    if (e->g->barrier()) return 1;
+    memcpy(buf, acc.data(), count * 8);
+    return 0;
+}
+int local_all_gather(void *ctx, const void *send, void *recv, size_t bytes) {
+    LocalEnd *e = (LocalEnd *)ctx;
+    e->g->ptr[(size_t)e->rank] = send;
+    if (e->g->barrier()) return 1;
+    for (int r = 0; r < e->g->nranks; r++) memcpy((char *)recv + (size_t)r * bytes, e->g->ptr[(size_t)r], bytes);
+    return e->g->barrier();
+}
+int local_gather(void *ctx, const void *send, void *recv, size_t bytes, int root) {
+    LocalEnd *e = (LocalEnd *)ctx;
+    e->g->ptr[(size_t)e->rank] = send;
+    if (e->g->barrier()) return 1;
+    if (e->rank == root)
+        for (int r = 0; r < e->g->nranks; r++) memcpy((char *)recv + (size_t)r * bytes, e->g->ptr[(size_t)r], bytes);
+    return e->g->barrier();
+}
+int local_broadcast(void *ctx, void *buf, size_t bytes, int root) {
+    LocalEnd *e = (LocalEnd *)ctx;
+    if (e->rank == root) e->g->ptr[(size_t)root] = buf;
+    if (e->g->barrier()) return 1;
+    if (e->rank != root) memcpy(buf, e->g->ptr[(size_t)root], bytes);
+    return e->g->barrier();
+}
+}  // namespace
+
 struct zk_comm {
-    int kind;                 // 0 = RCCL, 1 = host callbacks
+    int kind;                 // 0 = RCCL, 1 = host callbacks (kind 1 with `local` set: the ranks are threads of this process)
     int nranks, rank;
     ncclComm_t nccl;
     zk_comm_host_ops ops;
     uint64_t bytes_rx, ncoll;
     std::vector<uint8_t> hs, hr;     // host staging of the callback kind
+    LocalEnd *local = nullptr;
 
     int all_reduce_i64(void *dev, size_t count) {
         ncoll++;
@@ -441,15 +513,39 @@ int zk_comm_from_host_ops(const zk_comm_host_ops *ops, int nranks, int rank, zk_
     *out = new zk_comm{1, nranks, rank, nullptr, *ops, 0, 0, {}, {}};
     return ZK_OK;
 }
+int zk_comm_local_group_new(int nranks, zk_comm_local_group **out) {
+    if (!out || nranks < 1 || nranks > 1024) return ZK_E_ARG;
+    *out = new zk_comm_local_group(nranks);
+    return ZK_OK;
+}
+int zk_comm_local_group_free(zk_comm_local_group *g) {
+    delete g;
+    return ZK_OK;
+}
+int zk_comm_local_group_abort(zk_comm_local_group *g) {
+    if (!g) return ZK_E_ARG;
+    g->abort();
+    return ZK_OK;
+}
+int zk_comm_from_local_group(zk_comm_local_group *g, int rank, zk_comm **out) {
+    if (!g || !out || rank < 0 || rank >= g->nranks) return ZK_E_ARG;
+    LocalEnd *e = new LocalEnd{g, rank};
+    zk_comm_host_ops ops{e, local_all_reduce, local_all_gather, local_gather, local_broadcast};
+    zk_comm *c = new zk_comm{1, g->nranks, rank, nullptr, ops, 0, 0, {}, {}};
+    c->local = e;
+    *out = c;
+    return ZK_OK;
+}
 int zk_comm_free(zk_comm *c) {
     if (!c) return ZK_OK;
     if (c->kind == 0 && c->nccl) (void)rccl().CommDestroy(c->nccl);
+    delete c->local;
     delete c;
     return ZK_OK;
 }
 int zk_comm_rank(const zk_comm *c) { return c ? c->rank : -1; }
 int zk_comm_size(const zk_comm *c) { return c ? c->nranks : -1; }
-const char *zk_comm_backend(const zk_comm *c) { return !c ? "" : c->kind == 0 ? "rccl" : "host-ops"; }
+const char *zk_comm_backend(const zk_comm *c) { return !c ? "" : c->kind == 0 ? "rccl" : c->local ? "local-threads" : "host-ops"; }
 int zk_comm_stats(const zk_comm *c, uint64_t *bytes_received, uint64_t *collectives) {
     if (!c) return ZK_E_ARG;
     if (bytes_received) *bytes_received = c->bytes_rx;
@@ -463,6 +559,21 @@ int zk_comm_all_reduce_sum_i64(zk_comm *c, void *dev_buf, size_t count) {
 int zk_comm_all_gather(zk_comm *c, const void *dev_send, void *dev_recv, size_t bytes) {
     if (!c || !dev_send || !dev_recv) return ZK_E_ARG;
     return c->all_gather(dev_send, dev_recv, bytes);
+}
+int zk_comm_host_exchange(zk_comm *c, int op, void *host_buf, void *host_recv, size_t n, int root) {
+    if (!c || !host_buf || c->kind != 1 || root < 0 || root >= c->nranks) return ZK_E_ARG;
+    if ((op == 1 || (op == 2 && c->rank == root)) && !host_recv) return ZK_E_ARG;
+    if (c->nranks == 1) {
+        if (op == 1 || op == 2) memcpy(host_recv, host_buf, n);
+        return op >= 0 && op <= 3 ? ZK_OK : ZK_E_ARG;
+    }
+    switch (op) {
+    case 0: ZK_CB(c->ops.all_reduce_sum_i64(c->ops.ctx, (int64_t *)host_buf, n), "all_reduce_sum_i64"); return ZK_OK;
+    case 1: ZK_CB(c->ops.all_gather(c->ops.ctx, host_buf, host_recv, n), "all_gather"); return ZK_OK;
+    case 2: ZK_CB(c->ops.gather(c->ops.ctx, host_buf, c->rank == root ? host_recv : nullptr, n, root), "gather"); return ZK_OK;
+    case 3: ZK_CB(c->ops.broadcast(c->ops.ctx, host_buf, n, root), "broadcast"); return ZK_OK;
+    }
+    return ZK_E_ARG;
 }
 int zk_comm_broadcast(zk_comm *c, void *dev_buf, size_t bytes, int root) {
     if (!c || !dev_buf || root < 0 || root >= c->nranks) return ZK_E_ARG;

@@ -742,6 +742,7 @@ template <class F> int round_evals(const zk_table *const *tables, size_t nprod, 
     ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
     void *res = (char *)part + esz * (size_t)grid * npts;
     ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
+    if (!out) return ZK_OK;                                            // enqueue only (measurements: the producer kernel alone)
     finish_sums_kernel<F><<<1, kBlock, 0, cur_stream()>>>(part, (size_t)grid, (int)npts, res);
     ZK_HIP(hipGetLastError());
     ZK_HIP(zk::memcpy_on_stream(out, res, esz * npts, hipMemcpyDeviceToHost));
@@ -1221,7 +1222,6 @@ int zk_sumcheck_basic_verify(const zk_table *table, const uint64_t *claimed_sum,
 
 int zk_sumpoly_round_evals(const zk_table *const *tables, size_t nprod, size_t nfac, uint64_t *out) {
     ZK_TRY(check_sumpoly(tables, nprod, nfac));
-    if (!out) return ZK_E_ARG;
     // the reference reduces with add_polynomials_element_wise (:134), which asserts > 1 (sum_polynomial.rs:58-61)
     if (nprod < 2 || nfac < 2) return ZK_E_NEED_TWO;
     ZK_TRY(require_device());
@@ -1231,7 +1231,7 @@ int zk_sumpoly_round_evals(const zk_table *const *tables, size_t nprod, size_t n
 int zk_sumpoly_fold_round_evals(const zk_table *const *in, zk_table *const *out, size_t nprod, size_t nfac, const uint64_t *value,
                                 uint64_t *out_evals) {
     ZK_TRY(check_sumpoly(in, nprod, nfac));
-    if (!out || !value || !out_evals) return ZK_E_ARG;
+    if (!out || !value) return ZK_E_ARG;
     if (nprod < 2 || nfac < 2) return ZK_E_NEED_TWO;
     size_t len = in[0]->len;
     if (len < 4) return ZK_E_ARG;
@@ -1247,10 +1247,13 @@ int zk_sumpoly_fold_round_evals(const zk_table *const *in, zk_table *const *out,
         void *part;
         ZK_TRY(scratch(esz * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
         void *res = (char *)part + esz * (size_t)grid * npts;
-        ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, load_el<F>(value), part, grid)));
-        finish_sums_kernel<F><<<1, kBlock, 0, cur_stream()>>>(part, (size_t)grid, (int)npts, res);
-        ZK_HIP(hipGetLastError());
-        ZK_HIP(zk::memcpy_on_stream(out_evals, res, esz * npts, hipMemcpyDeviceToHost));
+        // out_evals == NULL: the tables are folded and the kernel is only enqueued (no reduction, no read-back); skip_point1 as in the provers' large rounds
+        ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, load_el<F>(value), part, grid, nullptr, out_evals ? 0 : 1)));
+        if (out_evals) {
+            finish_sums_kernel<F><<<1, kBlock, 0, cur_stream()>>>(part, (size_t)grid, (int)npts, res);
+            ZK_HIP(hipGetLastError());
+            ZK_HIP(zk::memcpy_on_stream(out_evals, res, esz * npts, hipMemcpyDeviceToHost));
+        }
     });
     for (size_t k = 0; k < nprod * nfac; k++) out[k]->len = len / 2;
     return ZK_OK;

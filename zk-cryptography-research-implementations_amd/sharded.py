@@ -78,12 +78,18 @@ def _declare_host():
     lib.zk_comm_init_rccl.argtypes = [u8p, C.c_int, C.c_int, vpp]
     lib.zk_comm_from_host_ops.argtypes = [C.POINTER(HostOps), C.c_int, C.c_int, vpp]
     lib.zk_comm_free.argtypes = [L.vp]
+    lib.zk_comm_local_group_new.argtypes = [C.c_int, vpp]
+    lib.zk_comm_local_group_free.argtypes = [L.vp]
+    lib.zk_comm_local_group_abort.argtypes = [L.vp]
+    lib.zk_comm_from_local_group.argtypes = [L.vp, C.c_int, vpp]
     lib.zk_comm_backend.argtypes = [L.vp]
     lib.zk_comm_backend.restype = C.c_char_p
     lib.zk_comm_stats.argtypes = [L.vp, u64p, u64p]
     lib.zk_comm_all_reduce_sum_i64.argtypes = [L.vp, L.vp, L.sz]
     lib.zk_comm_all_gather.argtypes = [L.vp, L.vp, L.vp, L.sz]
     lib.zk_comm_broadcast.argtypes = [L.vp, L.vp, L.sz, C.c_int]
+    lib.zk_comm_host_exchange.argtypes = [L.vp, C.c_int, L.vp, L.vp, L.sz, C.c_int]
+    lib.zk_comm_host_exchange.restype = C.c_int
     lib.zk_sharded_sumcheck_basic_prove.argtypes = [L.vp, L.vp, C.c_int, u64p, u64p, u64p]
     lib.zk_sharded_sumcheck_gkr_prove.argtypes = [L.vp, vpp, L.sz, L.sz, u64p, L.vp, u64p, u64p, u64p]
     lib.zk_sharded_mle_evaluate.argtypes = [L.vp, L.vp, u64p, L.sz, u64p]
@@ -91,6 +97,7 @@ def _declare_host():
     lib.zk_sharded_kzg_open.argtypes = [L.vp, L.vp, L.vp, L.vp, u64p, L.sz, u64p, u64p]
     lib.zk_sharded_kzg_open.restype = C.c_int
     for name in ("zk_comm_unique_id", "zk_comm_init_rccl", "zk_comm_from_host_ops", "zk_comm_free", "zk_comm_stats",
+                 "zk_comm_local_group_new", "zk_comm_local_group_free", "zk_comm_local_group_abort", "zk_comm_from_local_group",
                  "zk_comm_all_reduce_sum_i64", "zk_comm_all_gather", "zk_comm_broadcast", "zk_sharded_sumcheck_basic_prove",
                  "zk_sharded_sumcheck_gkr_prove", "zk_sharded_mle_evaluate", "zk_sharded_msm_g1"):
         getattr(lib, name).restype = C.c_int
@@ -280,6 +287,97 @@ class Comm:
             self.close()
         except Exception:                                          # noqa: BLE001
             pass
+
+
+class LocalGroup:
+    """The ranks as THREADS of this process (include/zkmle.h zk_comm_local_group_*): what a one-process host with one thread per GPU
+    uses, and how more ranks than a one-GPU box allows processes (8-way config 5) are rehearsed on one device.  `comm(rank)` is
+    called by rank's thread and gives the same interface as Comm; `abort()` wakes every rank waiting in an exchange."""
+
+    def __init__(self, world):
+        import threading
+        lib = _declare_host()
+        self.world = world
+        self._h = C.c_void_p()
+        L.check(lib.zk_comm_local_group_new(world, C.byref(self._h)))
+        self._bar = threading.Barrier(world)
+
+    def comm(self, rank):
+        return LocalComm(self, rank)
+
+    def abort(self):
+        _declare_host().zk_comm_local_group_abort(self._h)
+        self._bar.abort()
+
+    def close(self):
+        if self._h is not None and L._lib is not None:
+            L.lib().zk_comm_local_group_free(self._h)
+        self._h = None
+
+
+class LocalComm:
+    """one thread's end of a LocalGroup; same surface as Comm for the product path (`native()`, stats, small host all-gathers)"""
+
+    def __init__(self, group, rank):
+        self.group_, self.rank, self.world = group, rank, group.world
+        self.bytes_received = 0
+        self.native_note = None
+        self._native = C.c_void_p()
+        L.check(_declare_host().zk_comm_from_local_group(group._h, rank, C.byref(self._native)))
+
+    def backend(self):
+        return "local-threads"
+
+    def native(self):
+        return self._native
+
+    def native_backend(self):
+        return _declare_host().zk_comm_backend(self._native).decode()
+
+    def native_stats(self):
+        rx, n = C.c_uint64(0), C.c_uint64(0)
+        L.check(_declare_host().zk_comm_stats(self._native, C.byref(rx), C.byref(n)))
+        return int(rx.value), int(n.value)
+
+    def barrier(self):
+        self.group_._bar.wait()
+
+    def _xchg(self, op, buf, recv, n, root=0):
+        L.check(_declare_host().zk_comm_host_exchange(self._native, op, buf.ctypes.data_as(C.c_void_p),
+                                                      recv.ctypes.data_as(C.c_void_p) if recv is not None else None, n, root))
+
+    def all_gather(self, arr):
+        arr = np.ascontiguousarray(arr, np.uint64)
+        out = np.zeros((self.world,) + arr.shape, np.uint64)
+        self._xchg(1, arr, out, arr.nbytes)
+        self.bytes_received += (self.world - 1) * arr.nbytes
+        return out
+
+    def all_reduce_sum_i64(self, arr):
+        buf = np.ascontiguousarray(arr, np.int64).copy()
+        self._xchg(0, buf, None, buf.size)
+        return buf
+
+    def gather_bytes(self, data, root=0):
+        send = np.frombuffer(bytes(data), np.uint8).copy()
+        recv = np.zeros((self.world, len(send)), np.uint8) if self.rank == root else None
+        self._xchg(2, send, recv, len(send), root)
+        if self.rank != root:
+            return None
+        self.bytes_received += (self.world - 1) * len(send)
+        return [r.tobytes() for r in recv]
+
+    def broadcast_u64(self, arr, root=0):
+        buf = np.ascontiguousarray(arr, np.uint64).copy()
+        self._xchg(3, buf, None, buf.nbytes, root)
+        if self.rank != root:
+            self.bytes_received += buf.nbytes
+        return buf
+
+    def close(self):
+        if self._native is not None and L._lib is not None:
+            L.lib().zk_comm_free(self._native)
+        self._native = None
 
 
 # ---- per-shard engines -----------------------------------------------------------------------------
