@@ -301,10 +301,19 @@ typedef struct {
     uint64_t terms, entries, segments;
     float ms_digits, ms_sort, ms_buckets, ms_reduce, ms_total;    /* HIP-event times of the phases */
 } zk_msm_stats;
-/* sum_i [s_i] B_i by Pippenger (window_bits = 0: chosen from n).  scalars: Fr table of n terms
- * (n = bases length, any n >= 1).  This is the dot product of multilinear_kzg.rs:37-42 / :100-107. */
+/* sum_i [s_i] B_i by Pippenger (window_bits = 0: chosen from n; 2 .. 24).  scalars: Fr table of n terms
+ * (n = bases length, any n >= 1).  This is the dot product of multilinear_kzg.rs:37-42 / :100-107.
+ * Windows of more than 16 bits sort their entries most-significant-digit first (csrc/msm_sort_wide.cuh). */
 int zk_msm_g1(const zk_table *scalars, const zk_g1_bases *bases, int window_bits, uint64_t *out12,
               zk_msm_stats *stats /* may be NULL */);
+
+/* Optional, once per setup (TrustedSetup.g1_powers_of_tau is fixed across commits, trusted_setup.rs:5-8): keep one copy of the
+ * points per window, 2^(c w) B_i, so that every window of a later zk_msm_g1 / zk_kzg_commit on these bases feeds ONE bucket set:
+ * ceil(256 / c) bucket additions per term with c = 22 (window_bits = 0: chosen from n), one bucket reduction, no window
+ * combination.  Costs ceil(256 / c) x 128 bytes per point of HBM and (W - 1) c doublings per point to build; the group element
+ * returned by the MSM is the same.  A later call with another window size rebuilds the copies. */
+int zk_g1_bases_precompute(zk_g1_bases *b, int window_bits);
+int zk_g1_bases_precomputed_window(const zk_g1_bases *b);      /* 0: none */
 
 /* compute_lagrange_basis  trusted_setup.rs:24-49 : eq table of tau, built in HBM (O(2^n)) */
 int zk_kzg_lagrange_basis(const uint64_t *taus, size_t ntaus, zk_table **out);

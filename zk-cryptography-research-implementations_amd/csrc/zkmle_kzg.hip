@@ -14,6 +14,7 @@
 #define ZK_MSM_LIGHT_KERNELS
 #include "eq_table.cuh"
 #include "msm_kernels.cuh"
+#include "msm_sort_wide.cuh"
 
 using namespace zk;
 
@@ -21,6 +22,11 @@ struct zk_g1_bases {
     size_t n;
     void *dptr;            // n affine points, 96 B each (stored Montgomery form: what upload / download see)
     void *dptr_u = nullptr; // the same points pre-converted for the bucket kernel (128 B each), built on first use
+    // zk_g1_bases_precompute: one pre-converted copy of the points per window, [w][i] = 2^(pre_c w) B_i (w < pre_nwin), so that every
+    // window of an MSM feeds ONE bucket set (msm_core, `pre`)
+    void *pre_u = nullptr;
+    int pre_c = 0;
+    unsigned pre_nwin = 0;
 };
 struct zk_kzg_opening_key {
     // level[t] (t = 1..nvars): 2^(nvars - t) pre-summed affine bases B^(t)_k = sum_{h < 2^t} B_{h 2^(nvars-t) + k}
@@ -96,15 +102,60 @@ int bases_u(const zk_g1_bases *b, const void **out);
 // window, [w][i] = 2^(c w) B_i (c must be given): every window of MSM j feeds the SAME bucket set, so there are `batch` bucket
 // sets, one reduction each and no window combination.
 // results: `batch` XYZZ points on the host.
+// wide-window counting sort (msm_sort_wide.cuh): digits -> sorted entries (in `e1`) + per-bucket counts
+int msm_sort_wide(const void *d_scalars, size_t n, const WidePlan &pl, DevBuf &digits, DevBuf &e1, uint32_t *d_totals) {
+    const size_t cap = (size_t)pl.nwin * n;                 // entries, zero digits included
+    DevBuf k1, k2, hist1, off1, pstart1, hist2, off2, pstart2;
+    ZK_TRY(digits.alloc(cap * 4));                          // u32 digits; reused as the level-2 entry array
+    ZK_TRY(e1.alloc(cap * 4));                              // level-1 entries; reused as the final order
+    ZK_TRY(k1.alloc(cap * 2));
+    const size_t n1 = (size_t)pl.ctot1 * pl.nbins1;
+    ZK_TRY(hist1.alloc(n1 * 4));
+    ZK_TRY(off1.alloc(n1 * 8));
+    ZK_TRY(pstart1.alloc(((size_t)pl.nbins1 + 1) * 8));
+    msmw_digits_hist_kernel<<<pl.nchunks1, kWideBlock, ((size_t)pl.nwin << pl.hb1) * 4, cur_stream()>>>(d_scalars, n, pl, (uint32_t *)digits.p, (uint32_t *)hist1.p);
+    msmw_scan1_kernel<<<1, kWideBlock, 0, cur_stream()>>>((const uint32_t *)hist1.p, pl.nbins1, pl.ctot1, (uint64_t *)off1.p, (uint64_t *)pstart1.p);
+    msmw_l1_scatter_kernel<<<pl.nwin * pl.nchunks1, kWideBlock, 0, cur_stream()>>>((const uint32_t *)digits.p, n, pl, (const uint64_t *)off1.p, (uint32_t *)e1.p,
+                                                                                 (uint16_t *)k1.p);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipFuncSetAttribute((const void *)msmw_l3_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideFineLds));
+    ZK_HIP(hipFuncSetAttribute((const void *)msmw_l3_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideFineLds));
+    if (pl.mb > 0) {
+        const size_t n2 = (size_t)pl.ngroups * pl.c2;
+        ZK_TRY(k2.alloc(cap));
+        ZK_TRY(hist2.alloc(n2 * 4));
+        ZK_TRY(off2.alloc(n2 * 8));
+        ZK_TRY(pstart2.alloc((pl.ngroups + 1) * 8));
+        msmw_l2_hist_kernel<<<pl.nbins1 * pl.c2, 256, 0, cur_stream()>>>((const uint16_t *)k1.p, (const uint64_t *)pstart1.p, pl, (uint32_t *)hist2.p);
+        msmw_scan2_kernel<<<pl.nbins1, 256, 0, cur_stream()>>>((const uint32_t *)hist2.p, (const uint64_t *)pstart1.p, pl, (uint64_t *)off2.p, (uint64_t *)pstart2.p);
+        msmw_l2_scatter_kernel<<<pl.nbins1 * pl.c2, kWideBlock, 0, cur_stream()>>>((const uint32_t *)e1.p, (const uint16_t *)k1.p, (const uint64_t *)pstart1.p, pl,
+                                                                                  (const uint64_t *)off2.p, (uint32_t *)digits.p, (uint8_t *)k2.p);
+        msmw_l3_kernel<uint8_t><<<(unsigned)pl.ngroups, kWideBlock, kWideFineLds, cur_stream()>>>((const uint32_t *)digits.p, (const uint8_t *)k2.p, (const uint64_t *)pstart2.p,
+                                                                                                 pl.lb3, (uint32_t *)e1.p, d_totals);
+    } else {
+        // no middle level: a level-1 part is a group; level 3 must not write where it still reads, so the final order goes to `digits`
+        msmw_l3_kernel<uint16_t><<<(unsigned)pl.ngroups, kWideBlock, kWideFineLds, cur_stream()>>>((const uint32_t *)e1.p, (const uint16_t *)k1.p, (const uint64_t *)pstart1.p,
+                                                                                                  pl.lb3, (uint32_t *)digits.p, d_totals);
+        void *t = digits.p; digits.p = e1.p; e1.p = t;      // the caller finds the final order in `e1`
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(cur_stream()));             // the intermediates are freed on scope exit
+    return ZK_OK;
+}
+
 int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned batch, bool shifted, int c, G1Xyzz *result,
-             zk_msm_stats *stats) {
-    if (batch == 0 || (!shifted && batch != 1) || (shifted && n_sub != ((size_t)1 << (batch - 1)))) return ZK_E_ARG;
+             zk_msm_stats *stats, bool pre = false) {
+    if (batch == 0 || (!shifted && batch != 1) || (shifted && n_sub != ((size_t)1 << (batch - 1))) || (shifted && pre)) return ZK_E_ARG;
     const size_t n = shifted ? ((size_t)1 << batch) - 1 : n_sub;   // digit stream: [window][i]
     if (c == 0) c = pick_window(n_sub);
-    if (c < 2 || c > 16) return ZK_E_ARG;
+    // wide windows (msm_sort_wide.cuh): c > 16 -- more buckets than one workgroup's LDS counts -- and every MSM on precomputed
+    // window-shifted bases (`pre`: d_bases = [w][i], all windows feed ONE bucket set).  ZK_MSM_WIDE=1 forces the wide sort for c <= 16.
+    static const bool force_wide = [] { const char *e = getenv("ZK_MSM_WIDE"); return e && e[0] == '1'; }();
+    const bool wide = !shifted && (c > 16 || pre || (force_wide && c >= 9));
+    if (c < 2 || c > (wide ? 24 : 16)) return ZK_E_ARG;
     const unsigned nwin1 = (256 + c - 1) / c, nb = 1u << (c - 1);
-    if (n * (shifted ? nwin1 : 1) >= ((size_t)1 << 31)) return ZK_E_ARG;   // index + sign are packed in 32 bits
-    const unsigned nwin = shifted ? batch : nwin1;          // bucket sets
+    if (n * ((shifted || pre) ? nwin1 : 1) >= ((size_t)1 << 31)) return ZK_E_ARG;   // index + sign are packed in 32 bits
+    const unsigned nwin = shifted ? batch : pre ? 1u : nwin1;          // bucket sets
     const size_t nbuckets = (size_t)nwin * nb;
     // one (chunk, window) workgroup per CU-slot: long chunks make each workgroup write long runs per bucket
     // (r1: 128 chunks -> scatter 6.4 ms at 2^24; the LDS cursors hold a whole window either way)
@@ -127,16 +178,22 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     Events ev;
     ZK_TRY(ev.mark());
     DevBuf digits, hist, totals, starts, seg_starts, sorted, partials, A, R;
-    ZK_TRY(digits.alloc((size_t)nwin1 * n * 2));
-    ZK_TRY(hist.alloc((size_t)nwin1 * nchunks * nb * 4));
     ZK_TRY(totals.alloc(nbuckets * 4));
     ZK_TRY(starts.alloc((nbuckets + 1) * 8));
     ZK_TRY(seg_starts.alloc((nbuckets + 2) * 4));
+    size_t lds_bytes = (size_t)nb * 4;
+    if (wide) {
+        const WidePlan pl = wide_plan(n, (unsigned)c, nwin1, pre);
+        if (pl.nbins1 > 2048 || pl.nbuckets != nbuckets) return ZK_E_ARG;
+        ZK_TRY(ev.mark());                                   // (the digit kernel takes the first histogram with it: it counts as sort time)
+        ZK_TRY(msm_sort_wide(d_scalars, n, pl, digits, sorted, (uint32_t *)totals.p));
+    } else {
+    ZK_TRY(digits.alloc((size_t)nwin1 * n * 2));
+    ZK_TRY(hist.alloc((size_t)nwin1 * nchunks * nb * 4));
     msm_digits_kernel<<<grid_for(n), kBlock, 0, cur_stream()>>>(d_scalars, n, (unsigned)c, nwin1, (uint16_t *)digits.p);
     ZK_HIP(hipGetLastError());
     ZK_TRY(ev.mark());
     // counting sort, bucket counters staged in LDS
-    size_t lds_bytes = (size_t)nb * 4;
     ZK_HIP(hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     ZK_HIP(hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     msm_hist_kernel<<<nwin1 * nchunks, kSortBlock, lds_bytes, cur_stream()>>>((const uint16_t *)digits.p, n, (unsigned)c, nchunks, chunk_len, (uint32_t *)hist.p,
@@ -147,6 +204,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     else
         msm_chunk_scan_kernel<<<(unsigned)((nbuckets + kBlock - 1) / kBlock), kBlock, 0, cur_stream()>>>((uint32_t *)hist.p, nwin, nchunks, nb,
                                                                                                      (uint32_t *)totals.p);
+    }
     const uint32_t *d_totals = (const uint32_t *)totals.p;
     {
         unsigned ntiles = (unsigned)((nbuckets + kScanTile - 1) / kScanTile);
@@ -175,6 +233,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         memcpy(tail, (char *)stage + 8, 8);
     }
     uint32_t nseg = tail[0], max_segs = tail[1];
+    if (!wide) {
     ZK_TRY(sorted.alloc((entries ? entries : 1) * 4));
     static const int two_level_bits = [] { const char *e = getenv("ZK_MSM_TWO_LEVEL_BITS"); int k = e ? atoi(e) : 20; return k < 12 ? 12 : k; }();
     // measured r1 (sort phase, ms, one-level / two-level): 2^18 0.17 / 0.39, 2^19 0.35 / 0.37, 2^20 0.57 / 0.44, 2^21 0.91 / 0.63,
@@ -206,6 +265,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
                                                                         (const uint32_t *)hist.p, (const uint64_t *)starts.p, (uint32_t *)sorted.p,
                                                                         by_chunk);
         ZK_HIP(hipGetLastError());
+    }
     }
     ZK_TRY(ev.mark());
     // bucket sums
@@ -281,6 +341,8 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     }
     if (shifted) {                                          // the shifts live in the bases: bucket set j IS MSM j
         for (unsigned j = 0; j < batch; j++) result[j] = sums[j];
+    } else if (pre) {                                       // likewise: the one bucket set is the MSM
+        result[0] = sums[0];
     } else {                                                // window combination (host, W points): acc = 2^c * acc + S_w
         G1Xyzz acc = g1_xyzz_inf();
         for (int w = (int)nwin1 - 1; w >= 0; w--) {
@@ -306,6 +368,8 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
 
 // sum_i [s_i] B_i ; result as XYZZ on the host
 int msm_device(const void *d_scalars, const zk_g1_bases *bases, size_t n, int c, G1Xyzz *result, zk_msm_stats *stats) {
+    if (bases->pre_u && n == bases->n && (c == 0 || c == bases->pre_c))   // window-shifted copies exist: ONE bucket set (zk_g1_bases_precompute)
+        return msm_core(d_scalars, bases->pre_u, n, 1, false, bases->pre_c, result, stats, true);
     const void *d_bases = nullptr;
     ZK_TRY(bases_u(bases, &d_bases));                       // pre-converted points (cached on the handle)
     return msm_core(d_scalars, d_bases, n, 1, false, c, result, stats);
@@ -425,6 +489,7 @@ int zk_g1_bases_free(zk_g1_bases *b) {
     if (!b) return ZK_OK;
     if (b->dptr) ZK_HIP(hipFree(b->dptr));
     if (b->dptr_u) ZK_HIP(hipFree(b->dptr_u));
+    if (b->pre_u) ZK_HIP(hipFree(b->pre_u));
     delete b;
     return ZK_OK;
 }
@@ -474,6 +539,48 @@ int zk_msm_g1(const zk_table *scalars, const zk_g1_bases *bases, int window_bits
     affine_to_u64(g1_to_affine(r), out12);
     return ZK_OK;
 }
+
+// One pre-converted copy of the points per window, [w][i] = 2^(c w) B_i: every window of a later MSM on these bases then feeds ONE
+// bucket set -- W n bucket additions into 2^(c-1) buckets, ONE bucket reduction, no window combination -- which is what lets the window
+// grow to 22 bits (12 additions per term instead of 16).  Paid once per setup: (W - 1) c doublings per point, W x 128 bytes per point.
+int zk_g1_bases_precompute(zk_g1_bases *b, int window_bits) {
+    if (!b) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    int c = window_bits;
+    if (c == 0) {                                        // W n + 2.8 x 2^(c-1) addition-equivalents: 22 bits from 2^22 points up
+        const unsigned lg = ilog2(b->n);
+        c = lg >= 22 ? 22 : lg >= 18 ? 20 : lg >= 14 ? 16 : 13;
+    }
+    if (c < 9 || c > 24) return ZK_E_ARG;
+    const unsigned nwin = (256 + c - 1) / c;
+    if ((size_t)nwin * b->n >= ((size_t)1 << 31)) return ZK_E_ARG;
+    if (b->pre_u && b->pre_c == c) return ZK_OK;
+    if (b->pre_u) { ZK_HIP(hipFree(b->pre_u)); b->pre_u = nullptr; b->pre_c = 0; }
+    const size_t n = b->n;
+    void *tab = nullptr, *x0 = nullptr, *x1 = nullptr, *aff = nullptr;
+    ZK_HIP(hipMalloc(&tab, (size_t)nwin * n * kBaseUBytes));
+    struct Guard { void **p; ~Guard() { if (*p) (void)hipFree(*p); } } g0{&tab}, g1{&x0}, g2{&x1}, g3{&aff};
+    ZK_HIP(hipMalloc(&x0, n * sizeof(G1Xyzz)));
+    ZK_HIP(hipMalloc(&x1, n * sizeof(G1Xyzz)));
+    ZK_HIP(hipMalloc(&aff, n * sizeof(G1Affine)));
+    ZK_TRY(launch_g1_bases_to_u(b->dptr, n, tab, cur_stream()));                       // window 0: the points themselves
+    const void *src = b->dptr;
+    void *dst = x0, *other = x1;
+    for (unsigned w = 1; w < nwin; w++) {                                             // window w = c doublings of window w - 1
+        ZK_TRY(launch_g1_shift(src, w == 1 ? 0 : 1, n, (unsigned)c, dst, cur_stream()));
+        ZK_TRY(launch_batch_to_affine(dst, n, aff, cur_stream()));
+        ZK_TRY(launch_g1_bases_to_u(aff, n, (char *)tab + (size_t)w * n * kBaseUBytes, cur_stream()));
+        src = dst;
+        void *t = dst; dst = other; other = t;
+    }
+    ZK_HIP(hipStreamSynchronize(cur_stream()));
+    b->pre_u = tab;
+    b->pre_c = c;
+    b->pre_nwin = nwin;
+    tab = nullptr;                                       // kept
+    return ZK_OK;
+}
+int zk_g1_bases_precomputed_window(const zk_g1_bases *b) { return b ? b->pre_c : 0; }
 
 int zk_kzg_lagrange_basis(const uint64_t *taus, size_t ntaus, zk_table **out) {
     if (!out) return ZK_E_ARG;

@@ -27,6 +27,7 @@ def _decl():
         "zk_g1_bases_upload": [u64p, sz, C.POINTER(vp)], "zk_g1_bases_download": [vp, u64p], "zk_g1_bases_free": [vp],
         "zk_g1_bases_synthetic": [sz, u64p, u64p, C.POINTER(vp)], "zk_g1_generator": [u64p], "zk_g1_is_on_curve": [u64p],
         "zk_msm_g1": [vp, vp, C.c_int, u64p, C.POINTER(MsmStats)],
+        "zk_g1_bases_precompute": [vp, C.c_int], "zk_g1_bases_precomputed_window": [vp],
         "zk_kzg_lagrange_basis": [u64p, sz, C.POINTER(vp)], "zk_kzg_setup_g1": [u64p, sz, C.POINTER(vp)],
         "zk_kzg_commit": [vp, vp, u64p],
         "zk_kzg_opening_key_new": [vp, C.POINTER(vp)], "zk_kzg_opening_key_free": [vp],
@@ -72,6 +73,11 @@ class G1Bases:
         L.check(_decl().zk_g1_bases_synthetic(n, L.p64(np.ascontiguousarray(a, np.uint64)),
                                               L.p64(np.ascontiguousarray(d, np.uint64)), C.byref(h)))
         return cls(_handle=h)
+
+    def precompute(self, window_bits=0):
+        """one copy of the points per window (zk_g1_bases_precompute): later MSMs / commits on these bases use ONE bucket set"""
+        L.check(_decl().zk_g1_bases_precompute(self._h, window_bits))
+        return _decl().zk_g1_bases_precomputed_window(self._h)
 
     def __del__(self):
         if getattr(self, "_h", None):
