@@ -221,40 +221,82 @@ __global__ void msm_scan_apply_kernel(const uint32_t *__restrict__ totals, size_
     }
 }
 
-// regrouping scan (one block): out_starts = exclusive scan of ceil(segments(b) / group); out_starts[count] = total,
-// out_starts[count + 1] = the largest regrouped count.  Used by the hierarchical combination of heavy buckets.
-__global__ void msm_regroup_scan_kernel(const uint32_t *__restrict__ in_starts, size_t count, unsigned group,
-                                        uint32_t *__restrict__ out_starts) {
-    __shared__ uint32_t sh_s[kSortBlock];
-    __shared__ uint32_t sh_m[kSortBlock];
-    size_t per = (count + blockDim.x - 1) / blockDim.x;
-    size_t lo = (size_t)threadIdx.x * per, hi = lo + per < count ? lo + per : count;
-    uint32_t ss = 0, mx = 0;
-    for (size_t i = lo; i < hi; i++) {
-        uint32_t g = (in_starts[i + 1] - in_starts[i] + group - 1) / group;
-        ss += g;
-        mx = g > mx ? g : mx;
+// ---- partial-sum slots of the bucket kernel (msm_bucket.hip): a lane takes a RUN of `run` consecutive sorted entries, so bucket b
+// with range [s, s + n) gets one partial per run it overlaps: segs(b) = (s + n - 1) / run - s / run + 1 (0 when empty).  seg_starts =
+// exclusive scan of segs over all buckets; seg_starts[count] = total, seg_starts[count + 1] = the largest segs(b).  Same three-step
+// shape as the scan of the counts above, run after it (segs needs the bucket starts).
+struct SegFromRuns {                                     // partial slots of the bucket kernel
+    const uint64_t *starts;
+    unsigned run;
+    __device__ __forceinline__ uint32_t operator()(size_t i) const {
+        const uint64_t s = starts[i], e = starts[i + 1];
+        return e > s ? (uint32_t)((e - 1) / run - s / run + 1) : 0u;
     }
-    sh_s[threadIdx.x] = ss;
-    sh_m[threadIdx.x] = mx;
+};
+struct SegFromGroups {                                   // regrouping: sums of up to `group` consecutive partials of a bucket
+    const uint32_t *in_starts;
+    unsigned group;
+    __device__ __forceinline__ uint32_t operator()(size_t i) const { return (in_starts[i + 1] - in_starts[i] + group - 1) / group; }
+};
+template <class Fn>
+__global__ void msm_seg_tiles_kernel(Fn fn, size_t count, uint32_t *__restrict__ tile_s, uint32_t *__restrict__ tile_m) {
+    __shared__ uint32_t sh_s[kScanTile / 64], sh_m[kScanTile / 64];
+    const size_t i = (size_t)blockIdx.x * kScanTile + threadIdx.x;
+    uint32_t s = i < count ? fn(i) : 0u, m = s;
+    for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        const uint32_t om = __shfl_down(m, off, 64);
+        m = om > m ? om : m;
+    }
+    if ((threadIdx.x & 63) == 0) { sh_s[threadIdx.x >> 6] = s; sh_m[threadIdx.x >> 6] = m; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t rs = 0, rm = 0;
-        for (unsigned t = 0; t < blockDim.x; t++) {
-            uint32_t vs = sh_s[t];
-            sh_s[t] = rs;
-            rs += vs;
-            rm = sh_m[t] > rm ? sh_m[t] : rm;
-        }
-        out_starts[count] = rs;
-        out_starts[count + 1] = rm;
+        uint32_t ts = 0, tm = 0;
+        for (int w = 0; w < kScanTile / 64; w++) { ts += sh_s[w]; tm = sh_m[w] > tm ? sh_m[w] : tm; }
+        tile_s[blockIdx.x] = ts; tile_m[blockIdx.x] = tm;
     }
+}
+__global__ void msm_seg_totals_kernel(uint32_t *__restrict__ tile_s, const uint32_t *__restrict__ tile_m, unsigned ntiles, size_t count,
+                                      uint32_t *__restrict__ seg_starts) {
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const unsigned lane = threadIdx.x, per = (ntiles + 63u) / 64u;
+    const unsigned lo = lane * per < ntiles ? lane * per : ntiles, hi = lo + per < ntiles ? lo + per : ntiles;
+    uint32_t ss = 0, rm = 0;
+    for (unsigned t = lo; t < hi; t++) { ss += tile_s[t]; rm = tile_m[t] > rm ? tile_m[t] : rm; }
+    uint32_t ps = ss;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t us = __shfl_up(ps, off);
+        const uint32_t um = __shfl_xor(rm, off);
+        if ((int)lane >= off) ps += us;
+        rm = um > rm ? um : rm;
+    }
+    uint32_t rs = ps - ss;
+    for (unsigned t = lo; t < hi; t++) { const uint32_t vs = tile_s[t]; tile_s[t] = rs; rs += vs; }
+    if (lane == 63) { seg_starts[count] = ps; seg_starts[count + 1] = rm; }
+}
+template <class Fn>
+__global__ void msm_seg_apply_kernel(Fn fn, size_t count, const uint32_t *__restrict__ tile_s, uint32_t *__restrict__ seg_starts) {
+    __shared__ uint32_t sh_s[kScanTile];
+    const size_t i = (size_t)blockIdx.x * kScanTile + threadIdx.x;
+    const uint32_t v = i < count ? fn(i) : 0u;
+    sh_s[threadIdx.x] = v;
     __syncthreads();
-    ss = sh_s[threadIdx.x];
-    for (size_t i = lo; i < hi; i++) {
-        out_starts[i] = ss;
-        ss += (in_starts[i + 1] - in_starts[i] + group - 1) / group;
+    for (int off = 1; off < kScanTile; off <<= 1) {      // Hillis-Steele inclusive scan of the tile
+        const uint32_t as = threadIdx.x >= (unsigned)off ? sh_s[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh_s[threadIdx.x] += as;
+        __syncthreads();
     }
+    if (i < count) seg_starts[i] = tile_s[blockIdx.x] + sh_s[threadIdx.x] - v;
+}
+// seg_starts[0 .. count) = exclusive scan of fn(i); [count] = total, [count + 1] = max.  tile_s / tile_m: ceil(count / kScanTile) words each.
+template <class Fn>
+inline int msm_seg_scan(Fn fn, size_t count, uint32_t *tile_s, uint32_t *tile_m, uint32_t *seg_starts, hipStream_t s) {
+    const unsigned ntiles = (unsigned)((count + kScanTile - 1) / kScanTile);
+    msm_seg_tiles_kernel<Fn><<<ntiles, kScanTile, 0, s>>>(fn, count, tile_s, tile_m);
+    msm_seg_totals_kernel<<<1, 64, 0, s>>>(tile_s, tile_m, ntiles, count, seg_starts);
+    msm_seg_apply_kernel<Fn><<<ntiles, kScanTile, 0, s>>>(fn, count, tile_s, seg_starts);
+    return hipGetLastError() == hipSuccess ? ZK_OK : ZK_E_HIP;
 }
 
 // pass 3: scatter (index | sign << 31) into bucket order, cursors staged in LDS
@@ -452,7 +494,7 @@ __global__ void __launch_bounds__(kSortBlock) msm_fine_scatter_kernel(const uint
 // ---- heavy kernels live in their own translation units (compiled in parallel); launchers: ----------
 constexpr int kNormPer = 16;
 int launch_msm_bucket_sum(const void *bases, const uint32_t *sorted, const uint64_t *starts, const uint32_t *seg_starts,
-                          size_t nbuckets, unsigned seg_len, uint32_t nseg, void *partials, hipStream_t s);
+                          size_t nbuckets, unsigned run, uint64_t entries, void *partials, hipStream_t s);
 int launch_msm_partials_regroup(const void *in_partials, const uint32_t *in_starts, const uint32_t *out_starts, size_t nbuckets,
                                 unsigned group, uint32_t nout, void *out_partials, hipStream_t s);
 constexpr size_t kBaseUBytes = 128;   // one pre-converted affine point (g1u.cuh)
@@ -460,7 +502,7 @@ constexpr size_t kXyzzUBytes = 256;   // one XYZZ point in the internal form (g1
 int launch_msm_plain_level(void *A, void *B, unsigned nwin, unsigned cm1, unsigned k, size_t hh, size_t lh, hipStream_t s);
 int launch_msm_gather_cd(const void *A, const void *B, unsigned nwin, unsigned cm1, unsigned k, unsigned mbits, void *X, hipStream_t s);
 int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsigned mbits, void *out, hipStream_t s);
-int launch_msm_weighted_tail(void *X, void *Y, unsigned narrays, unsigned mbits, hipStream_t s);   // all weighted levels of the short arrays
+int launch_msm_weighted_tail(void *X, void *Y, unsigned narrays, unsigned mbits, hipStream_t s);   // all weighted levels of the short arrays (the wide first ones grid-wide)
 int launch_msm_window_sums(const void *A, const void *R, unsigned nwin, unsigned c, void *out, hipStream_t s);
 int launch_g1_bases_to_u(const void *affine, size_t n, void *out_u, hipStream_t s);
 int launch_g1_shift(const void *in, int in_is_xyzz, size_t n, unsigned c, void *out_xyzz, hipStream_t s);   // out = 2^c * in (stored affine or XYZZ in)

@@ -134,10 +134,10 @@ __global__ void msm_two_stage_out_kernel(const void *__restrict__ X, const void 
 // every level of the weighted reduction of the short arrays (X: values, Y: running weighted sums, M = 2^mbits entries each) in
 // ONE launch: a workgroup per array, a quad per item, __syncthreads between the levels (level after level as separate launches
 // cost ~8 us of launch, load and store latency each, on top of the arithmetic).  Same operations as msm_reduce_level_kernel.
-__global__ void __launch_bounds__(512) msm_weighted_tail_kernel(void *__restrict__ X, void *__restrict__ Y, unsigned mbits) {
+__global__ void __launch_bounds__(512) msm_weighted_tail_kernel(void *__restrict__ X, void *__restrict__ Y, unsigned mbits, size_t first_half) {
     const size_t base = (size_t)blockIdx.x << mbits;
     const unsigned quad = threadIdx.x >> 2, q = threadIdx.x & 3u, nquads = blockDim.x >> 2;
-    for (size_t half = (size_t)1 << (mbits - 1); half >= 1; half >>= 1) {
+    for (size_t half = first_half; half >= 1; half >>= 1) {
         for (size_t item = quad; item < 2 * half; item += nquads) {
             const bool second = item >= half;
             const size_t b = second ? item - half : item;
@@ -200,8 +200,13 @@ int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsign
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
+int launch_msm_reduce_level(void *A, void *R, unsigned nwin, unsigned c, size_t half, hipStream_t s);
 int launch_msm_weighted_tail(void *X, void *Y, unsigned narrays, unsigned mbits, hipStream_t s) {
-    msm_weighted_tail_kernel<<<narrays, 512, 0, s>>>(X, Y, mbits);
+    // a level of `half` pairs is 2 * half additions per array: the one-workgroup tail has 128 quads, so levels wider than that are
+    // throughput of ONE CU there (r3: 1.35 ms for two arrays of 2^11 entries) and go grid-wide instead, one launch each
+    size_t half = (size_t)1 << (mbits - 1);
+    for (; half > 64; half >>= 1) ZK_TRY(launch_msm_reduce_level(X, Y, narrays, mbits + 1, half, s));
+    msm_weighted_tail_kernel<<<narrays, 512, 0, s>>>(X, Y, mbits, half);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }

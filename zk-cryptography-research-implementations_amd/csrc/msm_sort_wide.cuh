@@ -38,12 +38,14 @@ inline WidePlan wide_plan(size_t n, unsigned c, unsigned nwin, bool one_set) {
     p.c = c; p.cb = c - 1; p.nwin = nwin; p.one_set = one_set ? 1u : 0u;
     p.hb1 = p.cb < kWideTopBits ? p.cb : kWideTopBits;
     p.kb1 = p.cb - p.hb1;
-    // level 3 sorts a whole group in ONE LDS tile when it fits: as few middle bits as keep the average group under 3/4 of a tile
-    // (at most 8 of either kind)
+    // level 3 takes groups of 2^lb3 = 256 buckets (fewer only when fewer bits are left): sparse buckets make a group fit ONE LDS tile
+    // (one pass), heavy buckets make it several tiles of >= 32 entries per bucket (count first, then tile by tile); in between, one more
+    // middle bit halves the groups into the one-tile case
     const size_t all_entries = (size_t)n * nwin;
     p.mb = p.kb1 > 8 ? p.kb1 - 8 : 0;
-    while (p.mb < 8 && p.mb < p.kb1 && (all_entries >> (p.hb1 + p.mb)) / (one_set ? 1u : nwin) > (size_t)kWideFineTile * 3 / 4) p.mb++;
     p.lb3 = p.kb1 - p.mb;
+    const size_t avg_group = (all_entries >> (p.hb1 + p.mb)) / (one_set ? 1u : nwin);
+    if (avg_group > (size_t)kWideFineTile * 3 / 4 && avg_group <= (size_t)2 * kWideFineTile && p.lb3 == 8 && p.mb < 8) { p.mb++; p.lb3--; }
     p.chunk_len1 = (n + 255) / 256;
     if (p.chunk_len1 < (size_t)kWideTile) p.chunk_len1 = kWideTile;
     p.nchunks1 = (unsigned)((n + p.chunk_len1 - 1) / p.chunk_len1);
@@ -115,14 +117,27 @@ __global__ void __launch_bounds__(kWideBlock) msmw_digits_hist_kernel(const void
     }
 }
 
-// ---- level-1 scan (one workgroup): absolute start of every (bin, chunk) run; pstart1[bin] = start of the bin's part ----------------
-__global__ void __launch_bounds__(kWideBlock) msmw_scan1_kernel(const uint32_t *__restrict__ hist1, unsigned nbins, unsigned ctot,
-                                                                uint64_t *__restrict__ off1, uint64_t *__restrict__ pstart1) {
+// ---- level-1 scan: absolute start of every (chunk, bin) run; pstart1[bin] = start of the bin's part -----------------------------
+// hist1 is chunk-major (row = chunk, column = bin).  Three steps: column sums of row slices (grid), scan over slices and bins (one
+// workgroup, <= 2048 bins x <= 64 slices), offsets (grid).  r3: as ONE workgroup walking whole columns it took 0.25 ms with 1664
+// bins and 1.0 ms with the 128 bins x 3072 rows of the one-bucket-set layout.
+constexpr unsigned kWideScanRows = 64;        // rows per slice
+__global__ void __launch_bounds__(256) msmw_scan1_sums_kernel(const uint32_t *__restrict__ hist1, unsigned nbins, unsigned ctot,
+                                                              uint64_t *__restrict__ slice_tot) {
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x, sl = blockIdx.y;
+    if (b >= nbins) return;
+    const unsigned r0 = sl * kWideScanRows, r1 = r0 + kWideScanRows < ctot ? r0 + kWideScanRows : ctot;
+    uint64_t s = 0;
+    for (unsigned k = r0; k < r1; k++) s += hist1[(size_t)k * nbins + b];
+    slice_tot[(size_t)sl * nbins + b] = s;
+}
+__global__ void __launch_bounds__(kWideBlock) msmw_scan1_bins_kernel(uint64_t *__restrict__ slice_tot, unsigned nbins, unsigned nslices,
+                                                                     uint64_t *__restrict__ pstart1) {
     __shared__ uint64_t tot[2048 + 1];
-    for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) {           // chunk-major rows: lane b reads column b, coalesced
-        uint64_t s = 0;
-        for (unsigned k = 0; k < ctot; k++) s += hist1[(size_t)k * nbins + b];
-        tot[b] = s;
+    for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) {           // column b: exclusive scan over its slices, total
+        uint64_t run = 0;
+        for (unsigned sl = 0; sl < nslices; sl++) { const uint64_t v = slice_tot[(size_t)sl * nbins + b]; slice_tot[(size_t)sl * nbins + b] = run; run += v; }
+        tot[b] = run;
     }
     __syncthreads();
     if (threadIdx.x == 0) {                                   // <= 2048 bins: a short serial prefix, once per MSM
@@ -132,10 +147,15 @@ __global__ void __launch_bounds__(kWideBlock) msmw_scan1_kernel(const uint32_t *
     }
     __syncthreads();
     for (unsigned b = threadIdx.x; b <= nbins; b += blockDim.x) pstart1[b] = tot[b];
-    for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) {
-        uint64_t run = tot[b];
-        for (unsigned k = 0; k < ctot; k++) { off1[(size_t)k * nbins + b] = run; run += hist1[(size_t)k * nbins + b]; }
-    }
+}
+__global__ void __launch_bounds__(256) msmw_scan1_offsets_kernel(const uint32_t *__restrict__ hist1, unsigned nbins, unsigned ctot,
+                                                                 const uint64_t *__restrict__ slice_tot, const uint64_t *__restrict__ pstart1,
+                                                                 uint64_t *__restrict__ off1) {
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x, sl = blockIdx.y;
+    if (b >= nbins) return;
+    const unsigned r0 = sl * kWideScanRows, r1 = r0 + kWideScanRows < ctot ? r0 + kWideScanRows : ctot;
+    uint64_t run = pstart1[b] + slice_tot[(size_t)sl * nbins + b];
+    for (unsigned k = r0; k < r1; k++) { off1[(size_t)k * nbins + b] = run; run += hist1[(size_t)k * nbins + b]; }
 }
 
 // ---- level-1 scatter: workgroup = (chunk, window); tile-sorted whole-run writes ------------------------------------------------------
@@ -218,7 +238,14 @@ __global__ void __launch_bounds__(256) msmw_l2_hist_kernel(const uint16_t *__res
     __syncthreads();
     uint64_t lo, hi;
     wide_slice(pstart1[part], pstart1[part + 1], j, p.c2, lo, hi);
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&cnt[k1[i] >> p.lb3], 1u);
+    // eight loads in flight per lane: one key per iteration is a chain of load latencies (r3: 0.67 ms for 2 x 10^8 two-byte keys)
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 8 * (uint64_t)blockDim.x) {
+        uint16_t k[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint64_t j = i + (uint64_t)u * blockDim.x; k[u] = j < hi ? k1[j] : (uint16_t)0xffffu; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint64_t j = i + (uint64_t)u * blockDim.x; if (j < hi) atomicAdd(&cnt[k[u] >> p.lb3], 1u); }
+    }
     __syncthreads();
     if (threadIdx.x < p.nb2) hist2[((size_t)part * p.nb2 + threadIdx.x) * p.c2 + j] = cnt[threadIdx.x];
 }
@@ -322,7 +349,13 @@ __global__ void __launch_bounds__(kWideBlock) msmw_l3_kernel(const uint32_t *__r
     if (!one_tile) {                                        // heavy group (skewed scalars): count first, then tile by tile
         for (unsigned l = threadIdx.x; l < 256; l += blockDim.x) cnt[l] = 0;
         __syncthreads();
-        for (uint64_t i = s + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&cnt[kin[i]], 1u);
+        for (uint64_t i = s + threadIdx.x; i < e; i += 8 * (uint64_t)blockDim.x) {      // eight loads in flight per lane
+            KT k[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint64_t j = i + (uint64_t)u * blockDim.x; k[u] = j < e ? kin[j] : (KT)0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint64_t j = i + (uint64_t)u * blockDim.x; if (j < e) atomicAdd(&cnt[k[u]], 1u); }
+        }
         __syncthreads();
         wide_bins_scan(cnt, cursor, nl, wave_tot);            // cursor[l] = offset of bucket l inside the group
         for (unsigned l = threadIdx.x; l < nl; l += blockDim.x) totals[g * nl + l] = cnt[l];

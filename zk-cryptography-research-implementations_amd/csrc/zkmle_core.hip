@@ -129,7 +129,7 @@ int pinned_pair(size_t bytes, void *out[2]) {
 struct PoolBlock { void *p; size_t cap; int dev; bool busy; hipStream_t stream; };   // stream = the one its last user ran on
 static std::vector<PoolBlock> g_pool;
 static size_t g_pool_bytes = 0;
-static const size_t kPoolLimit = (size_t)48 << 30;      // cached + in-use scratch per process
+static const size_t kPoolLimit = (size_t)96 << 30;      // cached + in-use scratch per process (a third of the 288 GB of HBM)
 
 int pool_alloc(size_t bytes, void **out) {
     if (bytes == 0) bytes = 16;

@@ -105,7 +105,7 @@ int bases_u(const zk_g1_bases *b, const void **out);
 // wide-window counting sort (msm_sort_wide.cuh): digits -> sorted entries (in `e1`) + per-bucket counts
 int msm_sort_wide(const void *d_scalars, size_t n, const WidePlan &pl, DevBuf &digits, DevBuf &e1, uint32_t *d_totals) {
     const size_t cap = (size_t)pl.nwin * n;                 // entries, zero digits included
-    DevBuf k1, k2, hist1, off1, pstart1, hist2, off2, pstart2;
+    DevBuf k1, k2, hist1, off1, pstart1, hist2, off2, pstart2, slice_tot;
     ZK_TRY(digits.alloc(cap * 4));                          // u32 digits; reused as the level-2 entry array
     ZK_TRY(e1.alloc(cap * 4));                              // level-1 entries; reused as the final order
     ZK_TRY(k1.alloc(cap * 2));
@@ -114,7 +114,15 @@ int msm_sort_wide(const void *d_scalars, size_t n, const WidePlan &pl, DevBuf &d
     ZK_TRY(off1.alloc(n1 * 8));
     ZK_TRY(pstart1.alloc(((size_t)pl.nbins1 + 1) * 8));
     msmw_digits_hist_kernel<<<pl.nchunks1, kWideBlock, ((size_t)pl.nwin << pl.hb1) * 4, cur_stream()>>>(d_scalars, n, pl, (uint32_t *)digits.p, (uint32_t *)hist1.p);
-    msmw_scan1_kernel<<<1, kWideBlock, 0, cur_stream()>>>((const uint32_t *)hist1.p, pl.nbins1, pl.ctot1, (uint64_t *)off1.p, (uint64_t *)pstart1.p);
+    {
+        const unsigned nslices = (pl.ctot1 + kWideScanRows - 1) / kWideScanRows;
+        const dim3 grid((pl.nbins1 + 255) / 256, nslices);
+        ZK_TRY(slice_tot.alloc((size_t)nslices * pl.nbins1 * 8));
+        msmw_scan1_sums_kernel<<<grid, 256, 0, cur_stream()>>>((const uint32_t *)hist1.p, pl.nbins1, pl.ctot1, (uint64_t *)slice_tot.p);
+        msmw_scan1_bins_kernel<<<1, kWideBlock, 0, cur_stream()>>>((uint64_t *)slice_tot.p, pl.nbins1, nslices, (uint64_t *)pstart1.p);
+        msmw_scan1_offsets_kernel<<<grid, 256, 0, cur_stream()>>>((const uint32_t *)hist1.p, pl.nbins1, pl.ctot1, (const uint64_t *)slice_tot.p,
+                                                                  (const uint64_t *)pstart1.p, (uint64_t *)off1.p);
+    }
     msmw_l1_scatter_kernel<<<pl.nwin * pl.nchunks1, kWideBlock, 0, cur_stream()>>>((const uint32_t *)digits.p, n, pl, (const uint64_t *)off1.p, (uint32_t *)e1.p,
                                                                                  (uint16_t *)k1.p);
     ZK_HIP(hipGetLastError());
@@ -217,6 +225,8 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
                                               (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
         msm_scan_apply_kernel<<<ntiles, kScanTile, 0, cur_stream()>>>(d_totals, nbuckets, seg_len, (const uint64_t *)te.p, (const uint32_t *)ts.p,
                                                      (uint64_t *)starts.p, (uint32_t *)seg_starts.p);
+        // partial-sum slots: one per run of seg_len sorted entries that overlaps the bucket (msm_bucket.hip); needs the bucket starts
+        ZK_TRY(msm_seg_scan(SegFromRuns{(const uint64_t *)starts.p, seg_len}, nbuckets, (uint32_t *)ts.p, (uint32_t *)tm.p, (uint32_t *)seg_starts.p, cur_stream()));
         ZK_HIP(hipGetLastError());
     }
     // the three totals the host needs to size what follows: both copies into pinned staging, ONE synchronisation (three before: ~60 us of
@@ -276,7 +286,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     if (c < 6) ZK_HIP(hipMemsetAsync(R.p, 0, red_bytes, cur_stream()));     // all-zero XYZZ = infinity (ZZ = 0); A (and, c >= 6, R) are written whole by the combine kernel
     if (nseg) {
         ZK_TRY(launch_msm_bucket_sum(d_bases, (const uint32_t *)sorted.p, (const uint64_t *)starts.p, (const uint32_t *)seg_starts.p,
-                                     nbuckets, seg_len, nseg, partials.p, cur_stream()));
+                                     nbuckets, seg_len, entries, partials.p, cur_stream()));
     }
     // heavy buckets (skewed scalars, or the short top window): combine partials 16 at a time until every
     // bucket has at most 16, so no lane ever runs a long serial chain of full additions
@@ -289,8 +299,13 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         ns.release();
         np.release();
         ZK_TRY(ns.alloc((nbuckets + 2) * 4));
-        msm_regroup_scan_kernel<<<1, kSortBlock, 0, cur_stream()>>>(cur_starts, nbuckets, kGroup, (uint32_t *)ns.p);
-        ZK_HIP(hipGetLastError());
+        {
+            const size_t ntiles = (nbuckets + kScanTile - 1) / kScanTile;
+            DevBuf ts, tm;
+            ZK_TRY(ts.alloc(ntiles * 4));
+            ZK_TRY(tm.alloc(ntiles * 4));
+            ZK_TRY(msm_seg_scan(SegFromGroups{cur_starts, kGroup}, nbuckets, (uint32_t *)ts.p, (uint32_t *)tm.p, (uint32_t *)ns.p, cur_stream()));
+        }
         ZK_HIP(zk::memcpy_on_stream(tail, (uint32_t *)ns.p + nbuckets, 8, hipMemcpyDeviceToHost));
         ZK_TRY(np.alloc(((size_t)tail[0] ? tail[0] : 1) * kXyzzUBytes));
         ZK_TRY(launch_msm_partials_regroup(cur_partials, cur_starts, (const uint32_t *)ns.p, nbuckets, kGroup, tail[0], np.p, cur_stream()));
