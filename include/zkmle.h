@@ -240,7 +240,9 @@ int zk_rounds_tail(zk_rounds *r, const zk_table *const *tables);
  * variables just absorbed, prover.rs:61-63 k times, and the 2^m_next segment sums of the output; m_next = 0: none) -> ...;
  * once the global table has <= 2048 entries, gather it on every rank and zk_rounds_multi_tail runs every round left (none of
  * them started) in one launch.  zk_rounds_multi_max = the largest m accepted, 0 when the handle cannot do this (mode 1, or the
- * transcript step on the device): use the one-round sequence above then.  Same messages, same bytes absorbed. */
+ * transcript step on the device): use the one-round sequence above then.  Same messages, same bytes absorbed.
+ * limbs_dev == NULL in zk_rounds_multi_evals / zk_rounds_multi_fold_evals (with m_next > 0) means ONE rank: nothing is all-reduced, the
+ * pass's last workgroup runs the exchange itself and the rounds count as absorbed (no zk_rounds_multi_absorb for them). */
 unsigned zk_rounds_multi_max(const zk_rounds *r);
 int zk_rounds_multi_evals(zk_rounds *r, const zk_table *table, unsigned m, uint64_t *limbs_dev);
 int zk_rounds_multi_absorb(zk_rounds *r, const uint64_t *limbs_dev, unsigned m);

@@ -15,12 +15,85 @@ namespace zk {
 
 // kMultiMax (mle_kernels.cuh) rounds per exchange: 2^4 segment sums fit the mailbox's `fin` area, 4 challenges come back
 
+// ---- the exchange inside the producer ----------------------------------------------------------------------------------------
+// r2 ran a one-workgroup kernel (multi_finish_kernel) behind every pass: reduce the partials, post, wait for the challenges.  r3: the
+// pass's LAST workgroup to finish does it.  Every workgroup adds its (reduced) partial sum to its segment's accumulator -- N 64-bit words,
+// word k = the sum of the partials' 32-bit limbs k: device-scope atomic adds, which meet at the memory side whatever XCD they come from --
+// drains them and adds 1 to a device-scope counter; the workgroup whose add returns gridDim.x - 1 knows that every partial has landed,
+// reads the 2^m x N words with device-scope loads, zeroes them for the next pass, propagates the carries and runs the exchange
+// (MI355X_MICROARCH.md, inter-workgroup visibility: agent-scope atomics both sides; the last arriver learns it from the value its add
+// returned; its other waves load behind a workgroup barrier).  No release / acquire fence: a release would write back the XCD's whole dirty
+// L2 -- the pass's own output -- once per workgroup.  The first form of this (r3) kept one partial per workgroup and let the last
+// workgroup gather the 2048 of them with sc1 loads: 6-15 us of dependent load rounds on the exchange's latency path.
+// Wave 0 alone runs this (the workgroup's other waves have left: no workgroup barrier holds their slots while the atomics drain);
+// `tot` is the workgroup's partial sum in lane 0 (block_reduce_wide's thread 0).
+template <class F>
+__device__ __forceinline__ void multi_finish_in_producer(const MultiFin &f, unsigned bps, const Fe<F> &tot, Fe<F> *ev, MultiFinShared *fs) {
+    constexpr int W = F::N + 1;
+    const unsigned lane = threadIdx.x & 63u, nseg = 1u << f.m;
+    unsigned last = 0;
+    if (lane == 0) {
+        // every accumulator word on a 128-byte line of its own: device-scope atomics to ONE line queue up behind each other at ~12 ns
+        // apiece whatever their addresses (r3: with the 16 x 8 words packed into nine lines a pass of 2048 workgroups lost 13-20 us to its
+        // 18 000 atomics, one of 8192 workgroups 100 us)
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(f.acc) + (size_t)(blockIdx.x / bps) * F::N * kMultiAccStride;
+#pragma unroll
+        for (int k = 0; k < F::N; k++)
+            __hip_atomic_fetch_add(acc + (size_t)k * kMultiAccStride, (unsigned long long)tot.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // two levels of arrival counters, each on a line of its own: the `bps` workgroups of a segment meet at the segment's counter, the
+        // last of each segment at the pass's.  ONE counter for all 2048 workgroups serialises them at ~11 ns per arrival (r3: +13 us on a
+        // 110 us pass, +90 us with 8192 workgroups).
+        unsigned *segc = f.counter + 16u * (1u + blockIdx.x / bps);
+        if (__hip_atomic_fetch_add(segc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == bps - 1u) {
+            __hip_atomic_store(segc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // left zero for the next launch (behind a kernel boundary)
+            if (__hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nseg - 1u) {
+                __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1u;
+            }
+        }
+    }
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
+    if (f.trace && lane == 0) f.trace[1] = wall_clock64();
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(f.acc);
+    for (unsigned i = lane; i < nseg * W; i += 64) {
+        const bool real = (i % W) < (unsigned)F::N;          // the top word of a segment only ever receives carries
+        unsigned long long *p = acc + ((size_t)(i / W) * F::N + (i % W)) * kMultiAccStride;
+        const unsigned long long v = real ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        if (real) __hip_atomic_store(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.limbs_out) f.limbs_out[i] = v;                 // sums of 32-bit limbs, carries unpropagated: what the all-reduce adds up
+        else fs->words[i] = v;
+    }
+    if (f.limbs_out) return;
+    wave_lds_sync();
+    for (unsigned seg = lane; seg < nseg; seg += 64) {
+        Wide<F> w;
+        unsigned long long c = 0;
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const unsigned long long v = fs->words[seg * W + k] + c;
+            w.l[k] = (uint32_t)v;
+            c = v >> 32;
+        }
+        ev[seg] = wide_reduce<F>(w);
+    }
+    wave_lds_sync();
+    if (f.trace && lane == 0) f.trace[2] = wall_clock64();
+    mailbox_post<F>(f.mb, f.mb->fin, ev, (int)nseg, f.seq, lane);
+    const Fe<F> r = mailbox_wait_challenges<F>(f.mb, f.seq, lane, (unsigned)f.m);
+    if ((int)lane < f.m) fe_store<F>(f.proof, f.chal_slot + f.per * lane, r);
+    if (f.trace && lane == 0) f.trace[3] = wall_clock64();
+}
+
 // partials[seg * bps + b] = sum over block b's share of segment seg (gridDim.x = nseg * bps)
 template <class F>
-__global__ void __launch_bounds__(kBlock) seg_sums_kernel(const void *__restrict__ in, size_t seglen, unsigned bps, void *__restrict__ partials) {
+__global__ void __launch_bounds__(kBlock) seg_sums_kernel(const void *__restrict__ in, size_t seglen, unsigned bps, void *__restrict__ partials, MultiFin fin) {
     __shared__ Wide<F> sh[kBlock / 64];
+    __shared__ Fe<F> ev[1 << kMultiMax];
+    __shared__ MultiFinShared fs;
     const unsigned seg = blockIdx.x / bps, bq = blockIdx.x % bps;
     const size_t base = (size_t)seg * seglen, stride = (size_t)bps * blockDim.x;
+    if (fin.trace && blockIdx.x == 0 && threadIdx.x == 0) fin.trace[0] = wall_clock64();
     Wide<F> acc[1] = {wide_zero<F>()};
     size_t t = (size_t)bq * blockDim.x + threadIdx.x;
     for (; t + 3 * stride < seglen; t += 4 * stride) {       // four loads in flight per lane
@@ -33,7 +106,10 @@ __global__ void __launch_bounds__(kBlock) seg_sums_kernel(const void *__restrict
     }
     for (; t < seglen; t += stride) wide_add_fe<F>(acc[0], fe_load<F>(in, base + t));
     Fe<F> tot;
-    if (block_reduce_wide<F, 1>(acc, sh, tot)) fe_store<F>(partials, blockIdx.x, tot);
+    const bool have = block_reduce_wide<F, 1>(acc, sh, tot);
+    if (fin.counter) {
+        if (threadIdx.x < 64) multi_finish_in_producer<F>(fin, bps, tot, ev, &fs);
+    } else if (have) fe_store<F>(partials, blockIdx.x, tot);
 }
 
 // One workgroup of 2^m waves, wave w owns segment w: reduce its partials (or take the all-reduced limbs), then wave 0 posts the 2^m sums

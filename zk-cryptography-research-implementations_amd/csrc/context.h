@@ -35,6 +35,16 @@ int require_device();
 hipStream_t cur_stream();
 hipError_t memcpy_on_stream(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);   // async copy + stream sync
 hipError_t memset_on_stream(void *dst, int value, size_t bytes);
+// wait until the current stream has drained, polling hipStreamQuery for the first ~0.3 ms (a blocking hipStreamSynchronize wakes up
+// 20-30 us after the last kernel has ended: a quarter of a small proof) before falling back to it
+hipError_t stream_wait_idle();
+// one block of words per thread and device, zero when handed out: the arrival counter (first 64 bytes) and the segment accumulators of
+// the passes that run their exchange themselves (basic_multi.cuh MultiFin).  Whoever uses it leaves it zero; sync_words_reset() after a
+// proof that may not have.
+constexpr size_t kSyncCounterBytes = 64 * (1 + 256);        // the pass's counter and one per segment, 64 bytes apart
+constexpr size_t kSyncWordsBytes = kSyncCounterBytes + (size_t)256 * 12 * 128;   // + one 128-byte line per (segment, limb) accumulator word
+int sync_words(void **out);
+int sync_words_reset();
 // device scratch for reduction partials: at least `bytes` bytes, owned per device, reused
 int scratch(size_t bytes, void **out);
 // pinned host staging for small results (a few field elements)

@@ -1,28 +1,36 @@
 // fold_multi.h -- host-side launcher of foldk_seg_sums_kernel (mle_kernels.cuh): several variables of a table folded in one pass.
 #pragma once
+#include <stdlib.h>
 #include "context.h"
 #include "mle_kernels.cuh"
 
 namespace zk {
 
+inline unsigned multi_blocks() {                       // ZK_MULTI_BLOCKS overrides kMultiBlocks, for measurements
+    static const unsigned v = [] { const char *e = getenv("ZK_MULTI_BLOCKS"); int k = e ? atoi(e) : kMultiBlocks; return (unsigned)(k < 256 ? 256 : (k > 16384 ? 16384 : k)); }();
+    return v;
+}
 inline unsigned multi_bps(size_t seglen, int m) {
     size_t b = (seglen + kBlock - 1) / kBlock;
-    const size_t cap = (size_t)kMultiBlocks >> m;
+    const size_t cap = (size_t)multi_blocks() >> m;
     return (unsigned)(b > cap ? cap : b < 1 ? 1 : b);
 }
-// fold the k variables whose values sit at rp[0 .. k) (device memory) and leave 2^m_next segment sums of the output (m_next = 0: none)
-template <class F> int launch_foldk(const void *in, void *out, size_t n, int k, const void *const *rp, int m_next, void *part, unsigned *bps_out) {
+// fold the k variables whose values sit at rp[0 .. k) (device memory) and leave 2^m_next segment sums of the output (m_next = 0: none).
+// FIN (translation units that include basic_multi.cuh): with `fin`, the pass's last workgroup runs the exchange on those sums itself.
+template <class F, bool FIN = false>
+int launch_foldk(const void *in, void *out, size_t n, int k, const void *const *rp, int m_next, void *part, unsigned *bps_out, const MultiFin *fin = nullptr) {
     FoldKArgs a{};
     a.in = in; a.out = out; a.n = n;
     for (int i = 0; i < k; i++) a.r[i] = rp[i];
     a.partials = m_next ? part : nullptr;
     a.bps = multi_bps(n >> m_next, m_next);
     const unsigned grid = a.bps << m_next;
+    const MultiFin f = (FIN && fin && m_next) ? *fin : MultiFin{};
     switch (k) {
-        case 1: foldk_seg_sums_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(a); break;
-        case 2: foldk_seg_sums_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(a); break;
-        case 3: foldk_seg_sums_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(a); break;
-        case 4: foldk_seg_sums_kernel<F, 4><<<grid, kBlock, 0, cur_stream()>>>(a); break;
+        case 1: foldk_seg_sums_kernel<F, 1, FIN><<<grid, kBlock, 0, cur_stream()>>>(a, f); break;
+        case 2: foldk_seg_sums_kernel<F, 2, FIN><<<grid, kBlock, 0, cur_stream()>>>(a, f); break;
+        case 3: foldk_seg_sums_kernel<F, 3, FIN><<<grid, kBlock, 0, cur_stream()>>>(a, f); break;
+        case 4: foldk_seg_sums_kernel<F, 4, FIN><<<grid, kBlock, 0, cur_stream()>>>(a, f); break;
         default: return ZK_E_ARG;
     }
     ZK_HIP(hipGetLastError());

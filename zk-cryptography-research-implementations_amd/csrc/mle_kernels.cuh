@@ -255,11 +255,33 @@ template <class F> __global__ void fold_half_sums_kernel(const void *__restrict_
 
 // ---- several variables folded in one pass (basic sumcheck rounds: basic_multi.cuh; evaluate: zkmle_core.hip) ----------------------------
 constexpr int kMultiMax = 4;            // variables per pass
-constexpr int kMultiBlocks = 2048;      // workgroups of a pass over a large table: (kMultiBlocks >> m) per segment of the output
+constexpr int kMultiBlocks = 1024;      // workgroups of a pass over a large table: (kMultiBlocks >> m) per segment of the output (r3 sweep: 1024-8192 within noise once the arrival atomics stopped sharing lines; 1024 = four workgroups per CU, one batch)
 
 // out[j] = the table folded by r[0] (top variable), r[1], ... r[K-1], j < n = len >> K: a binary tree over in[j + i n], i < 2^K, whose
 // level l pairs sub-trees 2^(K-1-l) entries apart (:61-63, K times).  Workgroups own one of the output's segments each (gridDim.x = nseg * bps)
 // and leave its partial sums when `partials` is given.
+// The exchange the LAST workgroup of a pass runs on the partials all its workgroups left (basic_multi.cuh; null counter: none).
+struct HostMailbox;
+struct MultiFin {
+    unsigned *counter;           // the pass's arrival counter, then one per segment, 16 words apart; zero before the launch and left zero
+    uint64_t *acc;               // 2^m x N words, kMultiAccStride words apart, zero before the launch and left zero: word (s, k) = the sum of limb k of segment s's partials
+    int m;                       // 2^m segments, `bps` workgroups each
+    uint64_t *limbs_out;         // sharded table: the 2^m sums leave as (N + 1) 32-bit limbs in 64-bit words for the all-reduce; nothing is posted
+    HostMailbox *mb;
+    uint64_t seq;
+    void *proof;
+    size_t chal_slot, per;       // challenge i goes to slot chal_slot + per i
+    uint64_t *trace;             // measurement (ZK_PROOF_TRACE=1): wall_clock64 at [0] a workgroup's start, [1] the last arrival, [2] the post, [3] the answer
+};
+constexpr size_t kMultiAccStride = 16;                       // in 64-bit words: one 128-byte line per accumulator word
+constexpr int kMultiFinWords = (1 << 4) * 13;                // (1 << kMultiMax) x (N + 1) for the widest field
+struct MultiFinShared {
+    unsigned last;
+    unsigned long long words[kMultiFinWords];
+};
+template <class F>
+__device__ __forceinline__ void multi_finish_in_producer(const MultiFin &f, unsigned bps, const Fe<F> &tot, Fe<F> *ev, MultiFinShared *fs);   // basic_multi.cuh
+
 struct FoldKArgs {
     const void *in;
     void *out;
@@ -325,10 +347,14 @@ template <class F> __device__ __forceinline__ Ufe<F> raw_mont_reduce(RawAcc<F> &
 }
 constexpr int kRawCarryEvery = 4;       // products between two normalizations: 4 L 2^58 + 2^30 < 2^64 for L <= 14
 
-template <class F, int K> __global__ void __launch_bounds__(kBlock) foldk_seg_sums_kernel(FoldKArgs a) {
+// FIN: the pass's last workgroup runs the exchange on the partials (`fin`; translation units that include basic_multi.cuh only)
+template <class F, int K, bool FIN = false> __global__ void __launch_bounds__(kBlock) foldk_seg_sums_kernel(FoldKArgs a, MultiFin fin) {
     __shared__ Wide<F> sh[kBlock / 64];
+    __shared__ Fe<F> fin_ev[FIN ? (1 << kMultiMax) : 1];
+    __shared__ MultiFinShared fin_fs[FIN ? 1 : 0 + 1];
     const unsigned nseg = gridDim.x / a.bps, seg = blockIdx.x / a.bps, bq = blockIdx.x % a.bps;
     const size_t seglen = a.n / nseg, base = (size_t)seg * seglen, stride = (size_t)a.bps * blockDim.x;
+    if (FIN && fin.trace && blockIdx.x == 0 && threadIdx.x == 0) fin.trace[0] = wall_clock64();
     Wide<F> acc[1] = {wide_zero<F>()};
     if constexpr (K <= 2) {
         Ufe<F> u[K];
@@ -373,7 +399,14 @@ template <class F, int K> __global__ void __launch_bounds__(kBlock) foldk_seg_su
     }
     if (a.partials == nullptr) return;
     Fe<F> tot;
-    if (block_reduce_wide<F, 1>(acc, sh, tot)) fe_store<F>(a.partials, blockIdx.x, tot);
+    const bool have = block_reduce_wide<F, 1>(acc, sh, tot);
+    if constexpr (FIN) {
+        if (fin.counter) {
+            if (threadIdx.x < 64) multi_finish_in_producer<F>(fin, a.bps, tot, fin_ev, &fin_fs[0]);
+            return;
+        }
+    }
+    if (have) fe_store<F>(a.partials, blockIdx.x, tot);
 }
 
 // ---- element-wise and tensor operations --------------------------------------------------------------

@@ -2,6 +2,7 @@
 // Product path only: every compute entry point runs HIP kernels; there is no CPU fallback.
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -21,12 +22,21 @@ hipError_t memcpy_on_stream(void *dst, const void *src, size_t bytes, hipMemcpyK
     return e != hipSuccess ? e : hipStreamSynchronize(g_stream);
 }
 hipError_t memset_on_stream(void *dst, int value, size_t bytes) { return hipMemsetAsync(dst, value, bytes, g_stream); }
+hipError_t stream_wait_idle() {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(g_stream);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 300.0) return hipStreamSynchronize(g_stream);
+    }
+}
 
 struct DeviceScratch {
     void *dev = nullptr;
     size_t dev_bytes = 0;
     void *host = nullptr;
     size_t host_bytes = 0;
+    void *syncw = nullptr;
     void *pair[2] = {nullptr, nullptr};      // pinned double buffer of the transcript absorb
     size_t pair_bytes = 0;
     void *mbox = nullptr, *mbox_dev = nullptr;   // coherent mailbox page (host-assisted transcript step)
@@ -39,6 +49,7 @@ struct ScratchSet {
     ~ScratchSet() {
         for (DeviceScratch &s : v) {
             if (s.dev) (void)hipFree(s.dev);
+            if (s.syncw) (void)hipFree(s.syncw);
             if (s.host) (void)hipHostFree(s.host);
             for (void *p : s.pair)
                 if (p) (void)hipHostFree(p);
@@ -78,6 +89,27 @@ int scratch(size_t bytes, void **out) {
         s->dev_bytes = want;
     }
     *out = s->dev;
+    return ZK_OK;
+}
+
+int sync_words(void **out) {
+    DeviceScratch *s;
+    ZK_TRY(current_scratch(&s));
+    if (!s->syncw) {
+        ZK_HIP(hipMalloc(&s->syncw, kSyncWordsBytes));
+        ZK_HIP(hipMemsetAsync(s->syncw, 0, kSyncWordsBytes, g_stream));
+        ZK_HIP(hipStreamSynchronize(g_stream));
+    }
+    *out = s->syncw;
+    return ZK_OK;
+}
+int sync_words_reset() {
+    DeviceScratch *s;
+    ZK_TRY(current_scratch(&s));
+    if (s->syncw) {
+        ZK_HIP(hipMemsetAsync(s->syncw, 0, kSyncWordsBytes, g_stream));
+        ZK_HIP(hipStreamSynchronize(g_stream));
+    }
     return ZK_OK;
 }
 

@@ -10,6 +10,7 @@
 // RCCL is opened with dlopen at first use (librccl.so.1): single-GPU users never load it.
 #include <dlfcn.h>
 #include <string.h>
+#include <time.h>
 
 #include <condition_variable>
 #include <mutex>
@@ -378,8 +379,16 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
     size_t L = tabs[0]->len;
     const size_t nrounds = ilog2(L) + ilog2(G);
     if (G > 1024 || !is_pow2(G)) return ZK_E_ARG;
+    // ZK_PROOF_TRACE=1 (measurement): host clock of this call's phases on stderr
+    static const bool trace = [] { const char *e = getenv("ZK_PROOF_TRACE"); return e && e[0] == '1'; }();
+    struct Clock {
+        bool on; double t0, last; static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+        void mark(const char *what) { if (!on) return; const double t = now(); fprintf(stderr, "[proof trace] %-28s +%7.1f us (%8.1f)\n", what, t - last, t - t0); last = t; }
+    } clk{trace, Clock::now(), 0};
+    clk.last = clk.t0;
     zk_rounds *r = nullptr;
     ZK_TRY(zk_rounds_new(field, mode, nprod, nfac, nrounds, t, &r));
+    clk.mark("rounds handle + init");
     struct Guard { zk_rounds *r; ~Guard() { zk_rounds_free(r); } } guard{r};
     DevBuf limbs;
     ZK_TRY(limbs.alloc(zk_rounds_limbs_len(r) * 8));
@@ -404,13 +413,19 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
             ZK_TRY(pong.alloc(field, L / 4 ? L / 4 : 1, 1));
             TableSet *dst = &ping, *other = &pong;
             unsigned m = pass(L * G);
-            ZK_TRY(zk_rounds_multi_evals(r, one, m, lp));
+            // one rank: nothing to all-reduce -- every pass's last workgroup runs the exchange itself (limbs = null)
+            uint64_t *xl = G > 1 ? lp : nullptr;
+            ZK_TRY(zk_rounds_multi_evals(r, one, m, xl));
             for (;;) {
-                ZK_TRY(c->all_reduce_i64(lp, ((size_t)1 << m) * W));       // the only exchange of these m rounds, on the stream
-                ZK_TRY(zk_rounds_multi_absorb(r, lp, m));
+                if (xl) {
+                    ZK_TRY(c->all_reduce_i64(lp, ((size_t)1 << m) * W));   // the only exchange of these m rounds, on the stream
+                    ZK_TRY(zk_rounds_multi_absorb(r, lp, m));
+                } else {
+                    c->ncoll++;                                            // (counted as the pass's exchange: zk_comm_stats)
+                }
                 const size_t n = L >> m;
                 const unsigned mn = n * G > kTail ? pass(n * G) : 0u;
-                ZK_TRY(zk_rounds_multi_fold_evals(r, one, dst->t[0], m, mn, lp));
+                ZK_TRY(zk_rounds_multi_fold_evals(r, one, dst->t[0], m, mn, xl));
                 one = dst->t[0];
                 TableSet *x = dst; dst = other; other = x;
                 L = n;
@@ -420,7 +435,10 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
         }
         if (G == 1) {
             ZK_TRY(zk_rounds_multi_tail(r, one));
-            return zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+            clk.mark("every round enqueued");
+            const int rc = zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+            clk.mark("collect");
+            return rc;
         }
         DevBuf rcv, rep;                                                   // global index = j G + rank
         ZK_TRY(rcv.alloc(G * L * esz));

@@ -137,6 +137,7 @@ static ServiceWorker &service_worker() {
     static thread_local ServiceWorker w;
     return w;
 }
+static thread_local bool g_last_proof_clean = false;        // the last proof of this thread saw every kernel's last post: nothing on the stream looks at the mailbox
 static thread_local int g_host_rounds_active = 0;           // one proof at a time per proving thread owns the mailbox and the worker
 
 // Whether the transcript step of a round runs on the host thread that drives the proof (dev_transcript.cuh HostMailbox: default) or on
@@ -154,6 +155,7 @@ static bool host_transcript_default() {
 template <class F> struct DeviceRounds {
     static constexpr size_t kHead = 256;               // DevSponge, padded
     DevBuf buf;
+    void *syncw = nullptr;                             // the arrival counter of the passes that run their exchange themselves (basic_multi.cuh MultiFin)
     size_t nbasis = 0, nslots = 0;
     std::vector<uint8_t> host;
     // host mode
@@ -182,6 +184,7 @@ template <class F> struct DeviceRounds {
         nbasis = basis_flat.size();
         nslots = slots;
         ZK_TRY(buf.alloc(bytes()));
+        ZK_TRY(sync_words(&syncw));
         host_mode = allow_host && host_transcript_default() && g_host_rounds_active == 0;
         void *h = nullptr, *d = nullptr;
         if (host_mode && host_mailbox(&h, &d) != ZK_OK) host_mode = false;   // no coherent pinned page on this system: the device runs the step
@@ -190,7 +193,10 @@ template <class F> struct DeviceRounds {
             owns_service = true;
             mb = (HostMailbox *)h;
             mb_dev = (HostMailbox *)d;
-            ZK_HIP(hipStreamSynchronize(cur_stream()));      // nothing of an earlier proof may still be looking at the mailbox
+            // nothing of an earlier proof may still be looking at the mailbox: a proof that ended cleanly has seen every kernel's last post
+            // (collect); anything else on this thread's stream -- a proof that failed, other work -- is waited for
+            if (!g_last_proof_clean) ZK_HIP(stream_wait_idle());
+            g_last_proof_clean = false;
             memset((void *)mb, 0, sizeof(HostMailbox));
             htr = &tr;
             hs.assign(nslots, fe_zero<F>());
@@ -414,6 +420,21 @@ template <class F> struct DeviceRounds {
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
+    // the same exchange run by the LAST workgroup of the pass that produces the segment sums (basic_multi.cuh multi_finish_in_producer):
+    // registers the request and hands back what that launch needs.  `limbs_out` instead: a sharded table's pass leaves the sums as limbs
+    // for the all-reduce and posts nothing (launch_multi with limbs_in follows the collective).
+    int multi_fin(int m, size_t round, MultiFin *out) {
+        if (!host_mode || m < 1 || m > kMultiMax) return ZK_E_ARG;
+        push_req(Req{kMulti, 0, m, round == 0 ? 1 : 0, 0, 0, 0, 1 + 3 * round, 3 + 3 * round, 0, {3, 0, 0, 0, 0, 0, 0}});
+        *out = MultiFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), m, nullptr, mb_dev, (uint64_t)nreq(), proof(), 3 + 3 * round, 3, nullptr};
+        static const bool trace = [] { const char *e = getenv("ZK_PROOF_TRACE"); return e && e[0] == '1'; }();
+        if (trace && nfin_traced < 8) {
+            if (!fin_trace.p) { ZK_TRY(fin_trace.alloc(8 * 4 * 8)); ZK_HIP(hipMemsetAsync(fin_trace.p, 0, 8 * 4 * 8, cur_stream())); }
+            out->trace = (uint64_t *)fin_trace.p + 4 * nfin_traced++;
+        }
+        return ZK_OK;
+    }
+    MultiFin multi_fin_limbs(int m, uint64_t *limbs_out) const { return MultiFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), m, limbs_out, nullptr, 0, nullptr, 0, 0, nullptr}; }
     // the 2^m segment sums as limbs for the all-reduce of a sharded table (nothing posted)
     int launch_multi_limbs(const void *partials, size_t count, int m, uint64_t *limbs_out) {
         if (m < 1 || m > kMultiMax) return ZK_E_ARG;
@@ -470,8 +491,16 @@ template <class F> struct DeviceRounds {
         traced_len = a.trace ? len : 0;
         return ZK_OK;
     }
-    DevBuf tail_trace;
+    DevBuf tail_trace, fin_trace;
     size_t traced_len = 0;
+    int nfin_traced = 0;
+    void print_fin_trace() {
+        uint64_t st[8 * 4];
+        if (!fin_trace.p || zk::memcpy_on_stream(st, fin_trace.p, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return;
+        for (int j = 0; j < nfin_traced; j++)
+            fprintf(stderr, "[proof trace]   exchange %d: pass %.1f us until the last workgroup arrived, sums + reduce %.1f us, post -> answer %.1f us\n", j,
+                    (double)(st[4 * j + 1] - st[4 * j]) * 0.01, (double)(st[4 * j + 2] - st[4 * j + 1]) * 0.01, (double)(st[4 * j + 3] - st[4 * j + 2]) * 0.01);
+    }
     void print_tail_trace(size_t len) {
         uint64_t st[6 * 16];
         if (zk::memcpy_on_stream(st, tail_trace.p, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return;
@@ -494,11 +523,22 @@ template <class F> struct DeviceRounds {
     // the single synchronisation of the sumcheck: proof slots + sponge back to the host
     int collect(Transcript &tr) {
         if (host_mode) {
+            static const bool trace = [] { const char *e = getenv("ZK_PROOF_TRACE"); return e && e[0] == '1'; }();
+            const double tc0 = now_ms();
             const int rc = close_service();
-            ZK_HIP(hipStreamSynchronize(cur_stream()));
+            const double tc1 = now_ms();
+            // Every byte of the proof is on the host once the service thread has answered the last request, and no kernel touches the
+            // mailbox after its last post (final posts are not acknowledged): the last kernel is retiring, its completion signal takes
+            // another ~16 us to arrive (r3 host trace).  A clean proof does not wait for it -- the next call's work is ordered behind it on
+            // the stream, and the next proof's mailbox reset races with nothing.
+            if (rc != ZK_OK || mb->aborted || trace) ZK_HIP(stream_wait_idle());
+            if (trace) fprintf(stderr, "[proof trace]   collect: service done +%.1f us, stream idle +%.1f us\n", (tc1 - tc0) * 1e3, (now_ms() - tc1) * 1e3);
+            if (rc != ZK_OK || mb->aborted) (void)sync_words_reset();     // a pass that gave up may have left its arrival counter half-way
             if (rc != ZK_OK) { set_last_error("host-assisted transcript step: the device did not post a round (aborted or stalled)"); return rc; }
             if (mb->aborted) { set_last_error("host-assisted transcript step: a kernel gave up waiting for the host"); return ZK_E_HIP; }
+            g_last_proof_clean = !trace;
             if (traced_len) print_tail_trace(traced_len);
+            if (nfin_traced) print_fin_trace();
             return ZK_OK;                                   // `tr` is the sponge the steps ran on
         }
         host.resize(bytes());
@@ -537,10 +577,10 @@ static int multi_pass_rounds(size_t global_len) {
     const int left = (int)ilog2(global_len) - (int)ilog2(kTailLen);
     return left < multi_kmax() ? left : multi_kmax();
 }
-template <class F> int launch_seg_sums(const void *in, size_t len, int m, void *part, unsigned *bps_out) {
+template <class F> int launch_seg_sums(const void *in, size_t len, int m, void *part, unsigned *bps_out, const MultiFin *fin = nullptr) {
     const size_t seglen = len >> m;
     const unsigned bps = multi_bps(seglen, m);
-    seg_sums_kernel<F><<<bps << m, kBlock, 0, cur_stream()>>>(in, seglen, bps, part);
+    seg_sums_kernel<F><<<bps << m, kBlock, 0, cur_stream()>>>(in, seglen, bps, part, fin ? *fin : MultiFin{});
     ZK_HIP(hipGetLastError());
     *bps_out = bps;
     return ZK_OK;
@@ -579,14 +619,17 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
         if (cl > kTailLen) {
             int m = multi_pass_rounds(cl);
             unsigned bps;
-            ZK_TRY((launch_seg_sums<F>(cur, cl, m, part, &bps)));          // :74-89, by 2^m segments
+            MultiFin fin;
+            // every pass's last workgroup runs the exchange on the segment sums the pass leaves: rounds round .. round + m - 1 (:50-58)
+            ZK_TRY(dr.multi_fin(m, round, &fin));
+            ZK_TRY((launch_seg_sums<F>(cur, cl, m, part, &bps, &fin)));    // :74-89, by 2^m segments
             for (;;) {
-                ZK_TRY(dr.launch_multi(part, bps, nullptr, m, round));     // rounds round .. round + m - 1 (:50-58), one exchange
                 const size_t n = cl >> m;
                 const int mn = n > kTailLen ? multi_pass_rounds(n) : 0;
                 const void *rp[kMultiMax];
                 for (int i = 0; i < m; i++) rp[i] = dr.slot_ptr(3 + 3 * (round + (size_t)i));
-                ZK_TRY((launch_foldk<F>(cur, dst, n, m, rp, mn, part, &bps)));   // :61-63 m times, fused with :74-89 of the next exchange
+                if (mn) ZK_TRY(dr.multi_fin(mn, round + (size_t)m, &fin));
+                ZK_TRY((launch_foldk<F, true>(cur, dst, n, m, rp, mn, part, &bps, mn ? &fin : nullptr)));   // :61-63 m times, fused with :74-89 and the exchange of the next rounds
                 cur = dst;
                 void *nx = other;
                 other = dst;
@@ -1024,14 +1067,19 @@ template <class F> struct RoundsImpl : RoundsBase {
         if (multi_max() == 0 || !t || t->field != F::ID || !is_pow2(t->len) || t->len < minlen) return ZK_E_ARG;
         return ZK_OK;
     }
+    // limbs == nullptr (here and in multi_fold_evals): ONE rank -- there is nothing to all-reduce, the pass's last workgroup runs the
+    // exchange itself and the rounds count as absorbed (no multi_absorb)
     int multi_evals(const zk_table *table, unsigned m, uint64_t *limbs) override {
         ZK_TRY(multi_table(table, 2));
-        if (!limbs || m < 1 || m > multi_max() || ((size_t)1 << m) > table->len || round + m > nrounds) return ZK_E_ARG;
+        if (m < 1 || m > multi_max() || ((size_t)1 << m) > table->len || round + m > nrounds) return ZK_E_ARG;
         void *part;
         ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
         unsigned bps;
-        ZK_TRY((launch_seg_sums<F>(table->dptr, table->len, (int)m, part, &bps)));
-        return dr.launch_multi_limbs(part, bps, (int)m, limbs);
+        MultiFin fin = dr.multi_fin_limbs((int)m, limbs);
+        if (!limbs) ZK_TRY(dr.multi_fin((int)m, round, &fin));
+        ZK_TRY((launch_seg_sums<F>(table->dptr, table->len, (int)m, part, &bps, &fin)));
+        if (!limbs) round += m;
+        return ZK_OK;
     }
     int multi_absorb(const uint64_t *limbs, unsigned m) override {
         if (!limbs || m < 1 || m > multi_max() || round + m > nrounds) return ZK_E_ARG;
@@ -1044,15 +1092,17 @@ template <class F> struct RoundsImpl : RoundsBase {
         if (k < 1 || k > multi_max() || k > round || ((size_t)1 << k) > in->len || m_next > multi_max()) return ZK_E_ARG;
         const size_t n = in->len >> k;
         if (!out || out->field != F::ID || out->len < n || out->dptr == in->dptr) return ZK_E_ARG;
-        if (m_next && (!limbs || ((size_t)1 << m_next) > n)) return ZK_E_ARG;
+        if (m_next && (((size_t)1 << m_next) > n || round + m_next > nrounds)) return ZK_E_ARG;
         void *part;
         ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
         const void *rp[kMultiMax];
         for (unsigned i = 0; i < k; i++) rp[i] = dr.slot_ptr(chal_base + per * (round - k + i));
         unsigned bps;
-        ZK_TRY((launch_foldk<F>(in->dptr, out->dptr, n, (int)k, rp, (int)m_next, part, &bps)));
+        MultiFin fin = dr.multi_fin_limbs((int)m_next, limbs);
+        if (m_next && !limbs) ZK_TRY(dr.multi_fin((int)m_next, round, &fin));
+        ZK_TRY((launch_foldk<F, true>(in->dptr, out->dptr, n, (int)k, rp, (int)m_next, part, &bps, m_next ? &fin : nullptr)));
         out->len = n;
-        if (m_next) ZK_TRY(dr.launch_multi_limbs(part, bps, (int)m_next, limbs));
+        if (m_next && !limbs) round += m_next;
         return ZK_OK;
     }
     // every remaining round on a table every rank holds in full (<= kTailLen entries); none of its rounds has started
