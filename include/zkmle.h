@@ -154,6 +154,11 @@ typedef struct {
     float ms_absorb, ms_rounds;
 } zk_sumcheck_stats;
 int zk_sumcheck_last_stats(zk_sumcheck_stats *out);
+/* Fault injection for tests: the NEXT proof (of any thread) whose transcript steps run on the host finds its host side deaf for
+ * `milliseconds` -- as if the process had been descheduled.  The kernels waiting for their challenge give up after their spin
+ * budget (2-3 s), every kernel still ends, and the proving call returns ZK_E_HIP with zk_last_error naming the cause; the
+ * thread's next proof works.  The reference has no analogue (its prover cannot stall: it is one thread). */
+int zk_debug_stall_service_once(int milliseconds);
 
 /* Prover::init + Prover::prove  prover.rs:22-71.  The table stays in HBM; per round one fused
  * fold + half-sums kernel; after the table absorb the transcript lives on the device (one host

@@ -122,3 +122,42 @@ def test_eight_way_msm_and_kzg_open_vs_oracle():
         assert np.array_equal(ev, want_ev), rank
         assert np.array_equal(proofs, want_proofs), rank
         assert np.array_equal(commit, want_commit) and np.array_equal(commit2, want_commit), rank
+
+
+def test_one_rank_whose_host_side_stalls_does_not_hang_the_others():
+    """Fault injection through the sharded prover (2 ranks as threads): the host side of ONE rank's proof is deaf for 3.5 s
+    (zk_debug_stall_service_once).  Its kernels give up and end, the rank keeps its place in every collective, BOTH ranks return within
+    seconds -- the stalled one with an error that names the cause -- and the next sharded proof on the same threads equals the oracle's."""
+    import time
+    zk = G.import_package()
+    from zkmle_amd import _lib
+    S = zk.sharded
+    field, world, logn = O.FR381, 2, 16
+    table = fill(zk, field, 1 << logn, 0xC5_0400)
+    want = O.sumcheck_basic_prove(field, table)
+
+    def body(rank, comm):
+        shard = S.GpuShard.from_array(field, S.shard_of(table, rank, world))
+        S.sumcheck_basic_prove_device(comm, shard)                 # warm-up: every rank has its service thread
+        comm.barrier()
+        if rank == 0:
+            _lib.check(zk.lib().zk_debug_stall_service_once(3500))
+        comm.barrier()
+        t0 = time.time()
+        err = None
+        try:
+            S.sumcheck_basic_prove_device(comm, shard)
+        except zk.ZkError as e:
+            err = str(e)
+        took = time.time() - t0
+        comm.barrier()
+        cs, rp, ch = S.sumcheck_basic_prove_device(comm, shard)
+        return err, took, cs, rp, ch
+
+    outs = run_ranks(world, on_own_stream(zk, body))
+    errs = [o[0] for o in outs]
+    assert any(e is not None for e in errs), "nobody noticed the stall"
+    assert all("host" in e.lower() for e in errs if e is not None), errs
+    for err, took, cs, rp, ch in outs:
+        assert took < 15.0, took
+        assert np.array_equal(cs, want[0]) and np.array_equal(rp, want[1]) and np.array_equal(ch, want[2])

@@ -137,6 +137,7 @@ static ServiceWorker &service_worker() {
     static thread_local ServiceWorker w;
     return w;
 }
+static std::atomic<int> g_stall_service_ms{0};               // zk_debug_stall_service_once
 static thread_local bool g_last_proof_clean = false;        // the last proof of this thread saw every kernel's last post: nothing on the stream looks at the mailbox
 static thread_local int g_host_rounds_active = 0;           // one proof at a time per proving thread owns the mailbox and the worker
 
@@ -324,6 +325,10 @@ template <class F> struct DeviceRounds {
     // the service thread's job for this proof: answer the requests in order as the kernels post them, until the proving thread has
     // closed the list and everything is answered.  Bounded: a kernel that gave up sets `aborted`; 8 s without a post ends the job.
     void service_loop() {
+        // fault injection (zk_debug_stall_service_once): the host side of ONE proof goes deaf for a while, as a descheduled or dying
+        // process would -- the kernels' spin budget must run out, every kernel must still end, the call must fail and say why
+        const int stall_ms = g_stall_service_ms.exchange(0);
+        if (stall_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(stall_ms));
         for (;;) {
             Req q;
             bool have;
@@ -1246,6 +1251,12 @@ int zk_uni_lagrange_interpolate(int field, const uint64_t *xs, const uint64_t *y
         std::vector<Fe<F>> c = lagrange_interpolate<F>(x, y);
         for (size_t i = 0; i < n; i++) store_el<F>(out + i * (F::N / 2), c[i]);
     });
+    return ZK_OK;
+}
+
+int zk_debug_stall_service_once(int milliseconds) {
+    if (milliseconds < 0) return ZK_E_ARG;
+    g_stall_service_ms.store(milliseconds);
     return ZK_OK;
 }
 
