@@ -476,9 +476,16 @@ def config5_leg(zk, env, args):
     # verifier equations (verifier.rs:47-70) on the proof just timed: claim chain + the table evaluated at the challenges
     ok, cur = verifier_equations_basic(zk, claimed, rp, ch)
     ok = ok and np.array_equal(S.mle_evaluate(comm, table, ch), cur)
-    # unavoidable HBM bytes of the round phase: the segment sums read the table once (32 B / entry); pass k of <= 4 rounds reads
-    # 16^-k of it again and writes 1/16 of what it read: 32 n (1 + 17/16 (1 + 1/16 + ...)) = 32 n (1 + 17/15)
-    traffic = 32.0 * n_global * (1 + 17.0 / 15.0)
+    # unavoidable HBM bytes of the round phase: the segment sums read the table once (32 B / entry); every pass of m rounds reads what is
+    # left again and writes 2^-m of it, down to the 2^11 entries of the one-workgroup tail (passes as csrc/zkmle_sumcheck.hip spreads them:
+    # at most 7 rounds each, evenly)
+    left, cur, traffic = args.log_n - 11, float(n_global), 32.0 * n_global
+    while left > 0:
+        passes = (left + 6) // 7
+        m = (left + passes - 1) // passes
+        traffic += 32.0 * cur * (1 + 2.0 ** -m)
+        cur /= 2 ** m
+        left -= m
     out["sumcheck"] = {"what": f"Prover::prove rounds of the 2^{args.log_n} table ({rp.shape[0]} rounds), 2^{args.log_n}/{world} entries per rank, "
                                "up to 4 rounds per pass over the shard: one all-reduce(SUM) of 2^m x 9 int64 words (m <= 4 rounds' segment sums) on the prover's stream per pass, replicated one-launch tail, transcript steps on each rank's host through the mailbox",
                        "ms_per_proof": dt * 1e3, "field_mul_per_s": (n_global - 1) / dt, "rounds": int(rp.shape[0]),

@@ -25,7 +25,7 @@ def main():
 
     bad, checked = [], 0
     # basic sumcheck (prover.rs:35-71): sizes that take 0, 1 and several passes of 1..4 rounds before the tail
-    for field, logns in ((0, (1, 3, 11, 12, 13, 14, 15, 16, 18)), (1, (2, 12, 14, 15)), (3, (13, 17))):
+    for field, logns in ((0, (1, 3, 11, 12, 13, 14, 15, 16, 18, 19, 20, 21)), (1, (2, 12, 14, 15, 19)), (3, (13, 17, 20))):
         for logn in logns:
             table = rand_table(field, 1 << logn, 4000 + logn)
             prover = zk.Prover.init(field, table)
@@ -39,7 +39,7 @@ def main():
     # the same prover through the sharded entry point on a one-rank communicator (zk_rounds_* handle)
     S = zk.sharded
     comm = S.Comm()
-    for logn in (5, 12, 13, 16):
+    for logn in (5, 12, 13, 16, 19, 20):
         table = rand_table(0, 1 << logn, 4100 + logn)
         cs, rp, ch = S.sumcheck_basic_prove_device(comm, S.GpuShard(zk.MultilinearPolynomial(0, table)), absorb_table=True)
         ecs, erp, ech = O.sumcheck_basic_prove(0, table)

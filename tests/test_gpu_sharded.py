@@ -160,14 +160,14 @@ def test_rounds_handle_several_rounds_per_pass_and_its_argument_checks():
     if kmax == 0:                                                 # ZK_HOST_TRANSCRIPT=0 in the environment: the one-round sequence applies
         lib.zk_rounds_free(r)
         pytest.skip("the transcript step runs on the device in this environment")
-    assert kmax == 4
-    assert lib.zk_rounds_limbs_len(r) * 8 <= 64 * 32
-    limbs = zk.MultilinearPolynomial.alloc(field, 64)             # device scratch for the limb words
+    assert kmax == 7                                              # ZK_BASIC_ROUNDS_PER_PASS default (kMultiMax = 8 is the ceiling)
+    assert lib.zk_rounds_limbs_len(r) * 8 <= 1024 * 32
+    limbs = zk.MultilinearPolynomial.alloc(field, 1024)           # device scratch for the limb words
     lp = lib.zk_table_device_ptr(limbs._h)
     t1 = zk.MultilinearPolynomial.alloc(field, n >> 3)
     t2 = zk.MultilinearPolynomial.alloc(field, n >> 4)
     E = L.ZK_E_ARG
-    assert lib.zk_rounds_multi_evals(r, poly._h, 5, lp) == E          # more rounds than the handle runs per pass
+    assert lib.zk_rounds_multi_evals(r, poly._h, 9, lp) == E          # more rounds than the handle runs per pass
     assert lib.zk_rounds_multi_evals(r, poly._h, 0, lp) == E
     assert lib.zk_rounds_multi_fold_evals(r, poly._h, t1._h, 3, 0, lp) == E   # nothing absorbed yet
     assert lib.zk_rounds_multi_tail(r, poly._h) == E                  # too long for the tail

@@ -13,7 +13,9 @@
 
 namespace zk {
 
-// kMultiMax (mle_kernels.cuh) rounds per exchange: 2^4 segment sums fit the mailbox's `fin` area, 4 challenges come back
+// kMultiMax (mle_kernels.cuh) = 8 rounds per exchange of a grid-wide pass: 2^8 segment sums go to the mailbox's `big` area, 8 challenges
+// come back, one answer line each.  The one-workgroup tail keeps four rounds per exchange (its sums and challenges live in LDS).
+constexpr int kTailMultiMax = 4;
 
 // ---- the exchange inside the producer ----------------------------------------------------------------------------------------
 // r2 ran a one-workgroup kernel (multi_finish_kernel) behind every pass: reduce the partials, post, wait for the challenges.  r3: the
@@ -25,11 +27,37 @@ namespace zk {
 // returned; its other waves load behind a workgroup barrier).  No release / acquire fence: a release would write back the XCD's whole dirty
 // L2 -- the pass's own output -- once per workgroup.  The first form of this (r3) kept one partial per workgroup and let the last
 // workgroup gather the 2048 of them with sc1 loads: 6-15 us of dependent load rounds on the exchange's latency path.
+// lane `lane` of wave 0 holds segment sums in registers and posts them itself: element `seg` of the mailbox's `big` area
+template <class F> __device__ __forceinline__ void multi_post_element(HostMailbox *mb, unsigned seg, const Fe<F> &e) {
+#pragma unroll
+    for (int k = 0; k < F::N; k++) mb->big[seg * 12 + k] = e.l[k];
+}
+// after every lane's multi_post_element: publish request `seq`, wait for the m challenges, store them
+template <class F> __device__ __forceinline__ void multi_publish_and_wait(const MultiFin &f, unsigned lane) {
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __atomic_store_n(&f.mb->gpu_seq, f.seq, __ATOMIC_RELEASE);
+    const Fe<F> r = mailbox_wait_challenges<F>(f.mb, f.seq, lane, (unsigned)f.m);
+    if ((int)lane < f.m) fe_store<F>(f.proof, f.chal_slot + f.per * lane, r);
+}
+// (N + 1) words holding sums of 32-bit limbs -> the field element
+template <class F> __device__ __forceinline__ Fe<F> limb_words_reduce(const unsigned long long (&v)[F::N + 1]) {
+    Wide<F> w;
+    unsigned long long c = 0;
+#pragma unroll
+    for (int k = 0; k <= F::N; k++) {
+        const unsigned long long x = v[k] + c;
+        w.l[k] = (uint32_t)x;
+        c = x >> 32;
+    }
+    return wide_reduce<F>(w);
+}
+
 // Wave 0 alone runs this (the workgroup's other waves have left: no workgroup barrier holds their slots while the atomics drain);
-// `tot` is the workgroup's partial sum in lane 0 (block_reduce_wide's thread 0).
+// `tot` is the workgroup's partial sum in lane 0 (block_reduce_wide's thread 0).  Everything stays in registers: lane l takes the
+// segments l, l + 64, ... (up to 2^8 of them).
 template <class F>
-__device__ __forceinline__ void multi_finish_in_producer(const MultiFin &f, unsigned bps, const Fe<F> &tot, Fe<F> *ev, MultiFinShared *fs) {
-    constexpr int W = F::N + 1;
+__device__ __forceinline__ void multi_finish_in_producer(const MultiFin &f, unsigned bps, const Fe<F> &tot) {
     const unsigned lane = threadIdx.x & 63u, nseg = 1u << f.m;
     unsigned last = 0;
     if (lane == 0) {
@@ -42,8 +70,7 @@ __device__ __forceinline__ void multi_finish_in_producer(const MultiFin &f, unsi
             __hip_atomic_fetch_add(acc + (size_t)k * kMultiAccStride, (unsigned long long)tot.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // two levels of arrival counters, each on a line of its own: the `bps` workgroups of a segment meet at the segment's counter, the
-        // last of each segment at the pass's.  ONE counter for all 2048 workgroups serialises them at ~11 ns per arrival (r3: +13 us on a
-        // 110 us pass, +90 us with 8192 workgroups).
+        // last of each segment at the pass's.  ONE counter for all 2048 workgroups serialises them at ~11 ns per arrival.
         unsigned *segc = f.counter + 16u * (1u + blockIdx.x / bps);
         if (__hip_atomic_fetch_add(segc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == bps - 1u) {
             __hip_atomic_store(segc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // left zero for the next launch (behind a kernel boundary)
@@ -55,42 +82,32 @@ __device__ __forceinline__ void multi_finish_in_producer(const MultiFin &f, unsi
     }
     if (!__builtin_amdgcn_readfirstlane(last)) return;
     if (f.trace && lane == 0) f.trace[1] = wall_clock64();
-    unsigned long long *acc = reinterpret_cast<unsigned long long *>(f.acc);
-    for (unsigned i = lane; i < nseg * W; i += 64) {
-        const bool real = (i % W) < (unsigned)F::N;          // the top word of a segment only ever receives carries
-        unsigned long long *p = acc + ((size_t)(i / W) * F::N + (i % W)) * kMultiAccStride;
-        const unsigned long long v = real ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        if (real) __hip_atomic_store(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (f.limbs_out) f.limbs_out[i] = v;                 // sums of 32-bit limbs, carries unpropagated: what the all-reduce adds up
-        else fs->words[i] = v;
+    for (unsigned seg = lane; seg < nseg; seg += 64) {
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(f.acc) + (size_t)seg * F::N * kMultiAccStride;
+        unsigned long long v[F::N + 1];
+#pragma unroll
+        for (int k = 0; k < F::N; k++) v[k] = __hip_atomic_load(acc + (size_t)k * kMultiAccStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[F::N] = 0;                                        // the top word only ever receives carries
+#pragma unroll
+        for (int k = 0; k < F::N; k++) __hip_atomic_store(acc + (size_t)k * kMultiAccStride, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.limbs_out) {                                   // sums of 32-bit limbs, carries unpropagated: what the all-reduce adds up
+#pragma unroll
+            for (int k = 0; k <= F::N; k++) f.limbs_out[(size_t)seg * (F::N + 1) + k] = v[k];
+        } else {
+            multi_post_element<F>(f.mb, seg, limb_words_reduce<F>(v));
+        }
     }
     if (f.limbs_out) return;
-    wave_lds_sync();
-    for (unsigned seg = lane; seg < nseg; seg += 64) {
-        Wide<F> w;
-        unsigned long long c = 0;
-#pragma unroll
-        for (int k = 0; k < W; k++) {
-            const unsigned long long v = fs->words[seg * W + k] + c;
-            w.l[k] = (uint32_t)v;
-            c = v >> 32;
-        }
-        ev[seg] = wide_reduce<F>(w);
-    }
-    wave_lds_sync();
     if (f.trace && lane == 0) f.trace[2] = wall_clock64();
-    mailbox_post<F>(f.mb, f.mb->fin, ev, (int)nseg, f.seq, lane);
-    const Fe<F> r = mailbox_wait_challenges<F>(f.mb, f.seq, lane, (unsigned)f.m);
-    if ((int)lane < f.m) fe_store<F>(f.proof, f.chal_slot + f.per * lane, r);
+    multi_publish_and_wait<F>(f, lane);
     if (f.trace && lane == 0) f.trace[3] = wall_clock64();
 }
 
-// partials[seg * bps + b] = sum over block b's share of segment seg (gridDim.x = nseg * bps)
+// partials[seg * bps + b] = sum over block b's share of segment seg (gridDim.x = nseg * bps); with `fin` the sums go to the pass's
+// accumulators instead and the last workgroup runs the exchange
 template <class F>
 __global__ void __launch_bounds__(kBlock) seg_sums_kernel(const void *__restrict__ in, size_t seglen, unsigned bps, void *__restrict__ partials, MultiFin fin) {
     __shared__ Wide<F> sh[kBlock / 64];
-    __shared__ Fe<F> ev[1 << kMultiMax];
-    __shared__ MultiFinShared fs;
     const unsigned seg = blockIdx.x / bps, bq = blockIdx.x % bps;
     const size_t base = (size_t)seg * seglen, stride = (size_t)bps * blockDim.x;
     if (fin.trace && blockIdx.x == 0 && threadIdx.x == 0) fin.trace[0] = wall_clock64();
@@ -108,58 +125,30 @@ __global__ void __launch_bounds__(kBlock) seg_sums_kernel(const void *__restrict
     Fe<F> tot;
     const bool have = block_reduce_wide<F, 1>(acc, sh, tot);
     if (fin.counter) {
-        if (threadIdx.x < 64) multi_finish_in_producer<F>(fin, bps, tot, ev, &fs);
+        if (threadIdx.x < 64) multi_finish_in_producer<F>(fin, bps, tot);
     } else if (have) fe_store<F>(partials, blockIdx.x, tot);
 }
 
-// One workgroup of 2^m waves, wave w owns segment w: reduce its partials (or take the all-reduced limbs), then wave 0 posts the 2^m sums
-// and stores the m challenges the host answers with.  With `limbs_out` the sums go out as (N + 1) 32-bit limbs in 64-bit words instead
-// (the element-wise all-reduce over the ranks of a sharded table adds them without carries) and nothing is posted.
+// The exchange behind an all-reduce (sharded table): one wave takes the summed limb words of the 2^m segments, posts the sums and stores the
+// m challenges the host answers with.
 struct MultiArgs {
-    const void *partials;
-    size_t count;                // partials[seg * count + i]
-    const uint64_t *limbs_in;    // non-null: the sums over the ranks of another launch's limbs_out
-    uint64_t *limbs_out;
+    const uint64_t *limbs_in;    // the sums over the ranks of the passes' limbs_out
     int m;
     HostMailbox *mb;
     uint64_t seq;
     void *proof;
     size_t chal_slot, per;       // challenge i goes to slot chal_slot + per i
 };
-template <class F> __global__ void __launch_bounds__(64 << kMultiMax) multi_finish_kernel(MultiArgs a) {
-    __shared__ Fe<F> ev[1 << kMultiMax];
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (a.limbs_in) {
-        if (lane == 0) {
-            Wide<F> w;
-            uint64_t c = 0;
+template <class F> __global__ void __launch_bounds__(64) multi_finish_kernel(MultiArgs a) {
+    const unsigned lane = threadIdx.x, nseg = 1u << a.m;
+    for (unsigned seg = lane; seg < nseg; seg += 64) {
+        unsigned long long v[F::N + 1];
 #pragma unroll
-            for (int k = 0; k <= F::N; k++) {                // words hold sums of 32-bit limbs: propagate the carries
-                const uint64_t v = a.limbs_in[wave * (F::N + 1) + k] + c;
-                w.l[k] = (uint32_t)v;
-                c = v >> 32;
-            }
-            ev[wave] = wide_reduce<F>(w);
-        }
-    } else {
-        Wide<F> acc[1] = {wide_zero<F>()};
-        for (size_t i = lane; i < a.count; i += 64) wide_add_fe<F>(acc[0], fe_load<F>(a.partials, (size_t)wave * a.count + i));
-        wave_reduce_wide<F, 1>(acc);
-        if (lane == 63) {
-            if (a.limbs_out) {
-#pragma unroll
-                for (int k = 0; k <= F::N; k++) a.limbs_out[wave * (F::N + 1) + k] = acc[0].l[k];
-            } else {
-                ev[wave] = wide_reduce<F>(acc[0]);
-            }
-        }
+        for (int k = 0; k <= F::N; k++) v[k] = a.limbs_in[(size_t)seg * (F::N + 1) + k];
+        multi_post_element<F>(a.mb, seg, limb_words_reduce<F>(v));
     }
-    if (a.limbs_out) return;
-    __syncthreads();
-    if (wave != 0) return;
-    mailbox_post<F>(a.mb, a.mb->fin, ev, 1 << a.m, a.seq, lane);
-    const Fe<F> r = mailbox_wait_challenges<F>(a.mb, a.seq, lane, (unsigned)a.m);
-    if ((int)lane < a.m) fe_store<F>(a.proof, a.chal_slot + a.per * lane, r);
+    const MultiFin f{nullptr, nullptr, a.m, nullptr, a.mb, a.seq, a.proof, a.chal_slot, a.per, nullptr};
+    multi_publish_and_wait<F>(f, lane);
 }
 
 // Every round of a table of <= kTailLen entries (none of them started), one workgroup: per exchange up to kMultiMax rounds -- segment sums,
@@ -175,15 +164,15 @@ struct BasicTailArgs {
     size_t chal_slot, per;       // of the tail's first round
 };
 template <class F> __global__ void __launch_bounds__(kTailBlock) basic_tail_kernel(BasicTailArgs a) {
-    __shared__ Fe<F> ev[1 << kMultiMax];
-    __shared__ Fe<F> ch[kMultiMax];
+    __shared__ Fe<F> ev[1 << kTailMultiMax];
+    __shared__ Fe<F> ch[kTailMultiMax];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const void *src = a.in;
     size_t cl = a.len, cs = a.chal_slot;
     uint64_t seq = a.seq0;
     while (cl >= 2) {
         const unsigned lg = 31u - (unsigned)__builtin_clz((unsigned)cl);
-        const unsigned m = lg < (unsigned)kMultiMax ? lg : (unsigned)kMultiMax, nseg = 1u << m;
+        const unsigned m = lg < (unsigned)kTailMultiMax ? lg : (unsigned)kTailMultiMax, nseg = 1u << m;
         const size_t seglen = cl >> m;
         if (seglen == 1) {
             if (tid < nseg) ev[tid] = fe_load<F>(src, tid);
@@ -197,7 +186,7 @@ template <class F> __global__ void __launch_bounds__(kTailBlock) basic_tail_kern
         }
         __syncthreads();
         if (wave == 0) {
-            mailbox_post<F>(a.mb, a.mb->fin, ev, (int)nseg, seq, lane);
+            mailbox_post<F>(a.mb, a.mb->big, ev, (int)nseg, seq, lane);
             if (seglen > 1) {
                 const Fe<F> r = mailbox_wait_challenges<F>(a.mb, seq, lane, m);
                 if (lane < m) {

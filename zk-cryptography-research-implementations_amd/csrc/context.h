@@ -49,7 +49,7 @@ int sync_words_reset();
 int scratch(size_t bytes, void **out);
 // pinned host staging for small results (a few field elements)
 int host_staging(size_t bytes, void **out);
-// one page of pinned, COHERENT (fine-grained) host memory per thread and device, mapped into the device: the mailbox of the
+// one block (16 KiB) of pinned, COHERENT (fine-grained) host memory per thread and device, mapped into the device: the mailbox of the
 // host-assisted transcript step (dev_transcript.cuh HostMailbox).  *host and *dev address the same memory.
 int host_mailbox(void **host, void **dev);
 

@@ -153,6 +153,7 @@ template <class F> __device__ __forceinline__ Fe<F> challenge_from_digest(const 
 // kernel that has reduced a round's evaluations writes them to the mailbox, bumps `gpu_seq` and spins (bounded) until the host thread that
 // is driving the proof has run the transcript step on its sponge (zkmle_sumcheck.hip HostRounds::service) and answered with the challenge.
 // The proving call polls instead of sleeping in hipStreamSynchronize; nothing else changes: same messages, same bytes absorbed.
+constexpr size_t kHostMailboxBytes = 16384;              // zkmle_core.hip host_mailbox allocates this much
 struct HostMailbox {
     uint64_t gpu_seq;                   // last request the GPU posted
     uint64_t pad0[15];
@@ -169,11 +170,13 @@ struct HostMailbox {
     // per round): dword 0 and dword 15 = the request number (low 32 bits), dwords 1 .. 12 = the challenge's limbs.  The host writes the
     // limbs first and the two tags last; a tag in each 32-byte half keeps the test sound even if the line were fetched as two halves.
     uint32_t ans[16];
-    uint32_t ans4[4][16];               // the same for an exchange that answers with up to four challenges (basic_multi.cuh): one line each
+    uint32_t ans8[8][16];               // the same for an exchange that answers with up to eight challenges (basic_multi.cuh): one line each
+    // an exchange of the basic sumcheck posts up to 2^8 segment sums (basic_multi.cuh): not part of what a proof's start resets
+    uint32_t big[256 * 12];
 };
 static_assert(offsetof(HostMailbox, ans) % 64 == 0, "the answer line must not straddle two lines");
-static_assert(offsetof(HostMailbox, ans4) % 64 == 0, "the answer lines must not straddle lines");
-static_assert(sizeof(HostMailbox) <= 4096, "the mailbox is one pinned page (zkmle_core.hip host_mailbox)");
+static_assert(offsetof(HostMailbox, ans8) % 64 == 0, "the answer lines must not straddle lines");
+static_assert(sizeof(HostMailbox) <= kHostMailboxBytes, "the mailbox is one pinned block (zkmle_core.hip host_mailbox)");
 constexpr long long kMailboxSpinBudget = 2000000;       // polls of ~0.7-1.5 us each: 1.5-3 s
 
 // wave 0, uniform: post `nel` elements from `src` (LDS) as request `seq`
@@ -220,16 +223,20 @@ template <class F> __device__ __forceinline__ Fe<F> mailbox_wait_challenge(HostM
     for (int i = 0; i < F::N; i++) e.l[i] = __builtin_amdgcn_readlane(v, 1 + i);
     return e;
 }
-// wave 0, uniform: the same for an exchange of m <= 4 challenges, one answer line each (all four lines are read by one load of the wave):
-// lane i < m returns challenge i
+// wave 0, uniform: the same for an exchange of m <= 8 challenges, one answer line each (four lines per load of the wave): lane i < m
+// returns challenge i
 template <class F> __device__ __forceinline__ Fe<F> mailbox_wait_challenges(HostMailbox *mb, uint64_t seq, unsigned lane, unsigned m) {
     const uint32_t tag = (uint32_t)seq;
-    uint32_t v = 0;
+    uint32_t v0 = 0, v1 = 0;
     long long spins = 0;
     for (;;) {
-        v = __hip_atomic_load(&mb->ans4[0][0] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v0 = __hip_atomic_load(&mb->ans8[0][0] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (m > 4) v1 = __hip_atomic_load(&mb->ans8[4][0] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         bool ok = true;
-        for (unsigned i = 0; i < m; i++) ok = ok && __builtin_amdgcn_readlane(v, 16 * i) == tag && __builtin_amdgcn_readlane(v, 16 * i + 15) == tag;
+        for (unsigned i = 0; i < m; i++) {
+            const uint32_t v = i < 4 ? v0 : v1;
+            ok = ok && __builtin_amdgcn_readlane(v, 16 * (i & 3u)) == tag && __builtin_amdgcn_readlane(v, 16 * (i & 3u) + 15) == tag;
+        }
         if (ok) break;
         int stop = 0;
         if (lane == 0 && ((++spins & 63) == 0)) {
@@ -243,7 +250,10 @@ template <class F> __device__ __forceinline__ Fe<F> mailbox_wait_challenges(Host
     Fe<F> e;
     const unsigned line = lane < m ? lane : 0u;
 #pragma unroll
-    for (int i = 0; i < F::N; i++) e.l[i] = (uint32_t)__shfl((int)v, (int)(16 * line + 1 + i));
+    for (int i = 0; i < F::N; i++) {
+        const uint32_t a = (uint32_t)__shfl((int)v0, (int)(16 * (line & 3u) + 1 + i)), b = (uint32_t)__shfl((int)v1, (int)(16 * (line & 3u) + 1 + i));
+        e.l[i] = line < 4 ? a : b;
+    }
     return e;
 }
 template <class F> __device__ __forceinline__ Fe<F> mailbox_element(const uint32_t *src) {

@@ -31,6 +31,15 @@ int launch_foldk(const void *in, void *out, size_t n, int k, const void *const *
         case 2: foldk_seg_sums_kernel<F, 2, FIN><<<grid, kBlock, 0, cur_stream()>>>(a, f); break;
         case 3: foldk_seg_sums_kernel<F, 3, FIN><<<grid, kBlock, 0, cur_stream()>>>(a, f); break;
         case 4: foldk_seg_sums_kernel<F, 4, FIN><<<grid, kBlock, 0, cur_stream()>>>(a, f); break;
+        case 5: case 6: case 7: case 8:
+            if constexpr (FIN) {                            // more than four variables per pass: the basic sumcheck only (zkmle_sumcheck.hip)
+                if (k == 5) foldk_seg_sums_kernel<F, 5, true><<<grid, kBlock, 0, cur_stream()>>>(a, f);
+                else if (k == 6) foldk_seg_sums_kernel<F, 6, true><<<grid, kBlock, 0, cur_stream()>>>(a, f);
+                else if (k == 7) foldk_seg_sums_kernel<F, 7, true><<<grid, kBlock, 0, cur_stream()>>>(a, f);
+                else foldk_seg_sums_kernel<F, 8, true><<<grid, kBlock, 0, cur_stream()>>>(a, f);
+                break;
+            }
+            return ZK_E_ARG;
         default: return ZK_E_ARG;
     }
     ZK_HIP(hipGetLastError());

@@ -254,7 +254,8 @@ template <class F> __global__ void fold_half_sums_kernel(const void *__restrict_
 }
 
 // ---- several variables folded in one pass (basic sumcheck rounds: basic_multi.cuh; evaluate: zkmle_core.hip) ----------------------------
-constexpr int kMultiMax = 4;            // variables per pass
+constexpr int kMultiMax = 8;            // variables per pass of the basic sumcheck (2^8 segment sums per exchange: basic_multi.cuh)
+constexpr int kEvalMultiMax = 4;        // variables per pass of evaluate (zkmle_core.hip)
 constexpr int kMultiBlocks = 1024;      // workgroups of a pass over a large table: (kMultiBlocks >> m) per segment of the output (r3 sweep: 1024-8192 within noise once the arrival atomics stopped sharing lines; 1024 = four workgroups per CU, one batch)
 
 // out[j] = the table folded by r[0] (top variable), r[1], ... r[K-1], j < n = len >> K: a binary tree over in[j + i n], i < 2^K, whose
@@ -274,13 +275,8 @@ struct MultiFin {
     uint64_t *trace;             // measurement (ZK_PROOF_TRACE=1): wall_clock64 at [0] a workgroup's start, [1] the last arrival, [2] the post, [3] the answer
 };
 constexpr size_t kMultiAccStride = 16;                       // in 64-bit words: one 128-byte line per accumulator word
-constexpr int kMultiFinWords = (1 << 4) * 13;                // (1 << kMultiMax) x (N + 1) for the widest field
-struct MultiFinShared {
-    unsigned last;
-    unsigned long long words[kMultiFinWords];
-};
 template <class F>
-__device__ __forceinline__ void multi_finish_in_producer(const MultiFin &f, unsigned bps, const Fe<F> &tot, Fe<F> *ev, MultiFinShared *fs);   // basic_multi.cuh
+__device__ __forceinline__ void multi_finish_in_producer(const MultiFin &f, unsigned bps, const Fe<F> &tot);   // basic_multi.cuh
 
 struct FoldKArgs {
     const void *in;
@@ -350,8 +346,6 @@ constexpr int kRawCarryEvery = 4;       // products between two normalizations: 
 // FIN: the pass's last workgroup runs the exchange on the partials (`fin`; translation units that include basic_multi.cuh only)
 template <class F, int K, bool FIN = false> __global__ void __launch_bounds__(kBlock) foldk_seg_sums_kernel(FoldKArgs a, MultiFin fin) {
     __shared__ Wide<F> sh[kBlock / 64];
-    __shared__ Fe<F> fin_ev[FIN ? (1 << kMultiMax) : 1];
-    __shared__ MultiFinShared fin_fs[FIN ? 1 : 0 + 1];
     const unsigned nseg = gridDim.x / a.bps, seg = blockIdx.x / a.bps, bq = blockIdx.x % a.bps;
     const size_t seglen = a.n / nseg, base = (size_t)seg * seglen, stride = (size_t)a.bps * blockDim.x;
     if (FIN && fin.trace && blockIdx.x == 0 && threadIdx.x == 0) fin.trace[0] = wall_clock64();
@@ -402,7 +396,7 @@ template <class F, int K, bool FIN = false> __global__ void __launch_bounds__(kB
     const bool have = block_reduce_wide<F, 1>(acc, sh, tot);
     if constexpr (FIN) {
         if (fin.counter) {
-            if (threadIdx.x < 64) multi_finish_in_producer<F>(fin, a.bps, tot, fin_ev, &fin_fs[0]);
+            if (threadIdx.x < 64) multi_finish_in_producer<F>(fin, a.bps, tot);
             return;
         }
     }

@@ -125,13 +125,16 @@ template <class F> __device__ __forceinline__ void prod_carry(ProdAcc<F> &acc) {
     }
 }
 // the three (or two) evaluation terms of one product of two factors at one pair index
-template <class F>
-__device__ __forceinline__ void accumulate_terms_lazy(const Fe<F> (&lo)[2], const Fe<F> (&hi)[2], ProdAcc<F> (&acc)[3], int skip1) {
+// SKIP1 (the point 1 is derived from the running claim, dev_transcript.cuh kDerive1): TWO accumulators instead of three -- 19 VGPRs less
+// across the loop, which is what keeps the first-round kernel under 128 VGPRs (4 waves per SIMD instead of 3; r3).  acc[0] = e(0),
+// acc[NACC - 1] = e(2), acc[1] = e(1) when it is evaluated.
+template <class F, bool SKIP1>
+__device__ __forceinline__ void accumulate_terms_lazy(const Fe<F> (&lo)[2], const Fe<F> (&hi)[2], ProdAcc<F> (&acc)[SKIP1 ? 2 : 3]) {
     const Ufe<F> l0 = u_from_limbs32<F>(lo[0]), l1 = u_from_limbs32<F>(lo[1]);
     const Ufe<F> h0 = u_from_limbs32<F>(hi[0]), h1 = u_from_limbs32<F>(hi[1]);
     prod_accumulate<F>(acc[0], l0, l1);
-    if (!skip1) prod_accumulate<F>(acc[1], h0, h1);
-    prod_accumulate<F>(acc[2], uadd<F>(h0, usub<F>(h0, l0)), uadd<F>(h1, usub<F>(h1, l1)));    // X(2) = 2 hi - lo (+ 4 p)
+    if constexpr (!SKIP1) prod_accumulate<F>(acc[1], h0, h1);
+    prod_accumulate<F>(acc[SKIP1 ? 1 : 2], uadd<F>(h0, usub<F>(h0, l0)), uadd<F>(h1, usub<F>(h1, l1)));    // X(2) = 2 hi - lo (+ 4 p)
 }
 // 2 L + 1 normalized 29-bit limbs -> 2 N + 2 saturated 32-bit words
 template <class F> struct ProdWide {
@@ -189,14 +192,16 @@ template <class F> __device__ __forceinline__ Fe<F> prodwide_reduce(const ProdWi
     return u_to_limbs32<F>(u_reduce_once<F>(umul<F>(sum, ru)));           // x 2^(29 L) / 2^(29 L): the same value, below 2 p
 }
 // workgroup totals of the lazily accumulated products -> partials, same layout as write_partials
-template <class F>
-__device__ __forceinline__ void write_partials_lazy(ProdAcc<F> (&acc)[3], ProdWide<F> *sh, void *partials, int skip1) {
+template <class F, bool SKIP1>
+__device__ __forceinline__ void write_partials_lazy(ProdAcc<F> (&acc)[SKIP1 ? 2 : 3], ProdWide<F> *sh, void *partials) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    constexpr int skip1 = SKIP1 ? 1 : 0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        if (k == 1 && skip1) continue;
-        prod_carry<F>(acc[k]);
-        ProdWide<F> v = prod_to_wide<F>(acc[k]);
+        if (k == 1 && SKIP1) continue;
+        ProdAcc<F> &a = acc[(SKIP1 && k == 2) ? 1 : k];
+        prod_carry<F>(a);
+        ProdWide<F> v = prod_to_wide<F>(a);
         prodwide_dpp_step<F, 0x111, 0xf>(v);
         prodwide_dpp_step<F, 0x112, 0xf>(v);
         prodwide_dpp_step<F, 0x114, 0xf>(v);
@@ -223,11 +228,14 @@ __device__ __forceinline__ void write_partials(Wide<F> (&acc)[NFAC + 1], Wide<F>
 }
 
 // tables of `2 * half` entries; partials[t * gridDim.x + block]
-template <class F, int NFAC>
-__global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials, int skip1 = 0) {
+template <class F, int NFAC, bool SKIP1 = false>
+__global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials) {
     if constexpr (NFAC == 2 && LazyProducts<F>::value) {
         __shared__ ProdWide<F> shp[3 * kBlock / 64];
-        ProdAcc<F> pacc[3] = {prod_zero<F>(), prod_zero<F>(), prod_zero<F>()};
+        constexpr int NACC = SKIP1 ? 2 : 3;
+        ProdAcc<F> pacc[NACC];
+#pragma unroll
+        for (int t = 0; t < NACC; t++) pacc[t] = prod_zero<F>();
         int pending = 0;
         const size_t pstride = (size_t)gridDim.x * blockDim.x;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += pstride) {
@@ -239,15 +247,15 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
                     lo[f] = fe_load<F>(tabs.in[p * 2 + f], i);
                     hi[f] = fe_load<F>(tabs.in[p * 2 + f], i + half);
                 }
-                accumulate_terms_lazy<F>(lo, hi, pacc, skip1);
+                accumulate_terms_lazy<F, SKIP1>(lo, hi, pacc);
                 if (++pending == kProdCarryEvery) {
                     pending = 0;
 #pragma unroll
-                    for (int t = 0; t < 3; t++) prod_carry<F>(pacc[t]);
+                    for (int t = 0; t < NACC; t++) prod_carry<F>(pacc[t]);
                 }
             }
         }
-        write_partials_lazy<F>(pacc, shp, partials, skip1);
+        write_partials_lazy<F, SKIP1>(pacc, shp, partials);
         return;
     }
     __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];
@@ -255,6 +263,8 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
 #pragma unroll
     for (int t = 0; t <= NFAC; t++) acc[t] = wide_zero<F>();
     size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int skip1 = SKIP1 ? 1 : 0;
+    (void)skip1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
         for (int p = 0; p < nprod; p++) {
             Fe<F> lo[NFAC], hi[NFAC];
@@ -272,12 +282,16 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
 
 // tables of 4q entries in, 2q out; lane i folds outputs i and i+q of every table, then uses them
 // as the (lo, hi) pair of the NEXT round.
-template <class F, int NFAC>
+template <class F, int NFAC, bool SKIP1>
 __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs, int nprod, size_t q, const Fe<F> &r, void *__restrict__ partials,
-                                                      const void *__restrict__ rp, int skip1) {
+                                                      const void *__restrict__ rp) {
+    constexpr int skip1 = SKIP1 ? 1 : 0;
     if constexpr (NFAC == 2 && LazyProducts<F>::value) {
         __shared__ ProdWide<F> shp[3 * kBlock / 64];
-        ProdAcc<F> pacc[3] = {prod_zero<F>(), prod_zero<F>(), prod_zero<F>()};
+        constexpr int NACC = SKIP1 ? 2 : 3;
+        ProdAcc<F> pacc[NACC];
+#pragma unroll
+        for (int t = 0; t < NACC; t++) pacc[t] = prod_zero<F>();
         int pending = 0;
         const size_t pstride = (size_t)gridDim.x * blockDim.x;
         const Multiplier<F> pmr(challenge_arg<F>(r, rp));
@@ -296,15 +310,15 @@ __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs,
                     fe_store<F>(dst, i, lo[f]);
                     fe_store<F>(dst, i + q, hi[f]);
                 }
-                accumulate_terms_lazy<F>(lo, hi, pacc, skip1);
+                accumulate_terms_lazy<F, SKIP1>(lo, hi, pacc);
                 if (++pending == kProdCarryEvery) {
                     pending = 0;
 #pragma unroll
-                    for (int t = 0; t < 3; t++) prod_carry<F>(pacc[t]);
+                    for (int t = 0; t < NACC; t++) prod_carry<F>(pacc[t]);
                 }
             }
         }
-        write_partials_lazy<F>(pacc, shp, partials, skip1);
+        write_partials_lazy<F, SKIP1>(pacc, shp, partials);
         return;
     }
     __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];
@@ -333,10 +347,10 @@ __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs,
     }
     write_partials<F, NFAC>(acc, sh, partials);
 }
-template <class F, int NFAC>
+template <class F, int NFAC, bool SKIP1 = false>
 __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials,
-                                                                  const void *__restrict__ rp = nullptr, int skip1 = 0) {
-    fold_round_evals_body<F, NFAC>(tabs, nprod, q, r, partials, rp, skip1);
+                                                                  const void *__restrict__ rp = nullptr) {
+    fold_round_evals_body<F, NFAC, SKIP1>(tabs, nprod, q, r, partials, rp);
 }
 // The same round for SHORT tables of products of two factors.  Below ~2^15 pair indices the launch above does not fill the
 // device and lasts as long as one lane's chain of products (14 for two products); here a wave takes ONE table for 64 consecutive

@@ -132,8 +132,8 @@ int host_mailbox(void **host, void **dev) {
     DeviceScratch *s;
     ZK_TRY(current_scratch(&s));
     if (!s->mbox) {
-        ZK_HIP(hipHostMalloc(&s->mbox, 4096, hipHostMallocCoherent | hipHostMallocMapped));
-        memset(s->mbox, 0, 4096);
+        ZK_HIP(hipHostMalloc(&s->mbox, 16384, hipHostMallocCoherent | hipHostMallocMapped));   // dev_transcript.cuh kHostMailboxBytes
+        memset(s->mbox, 0, 16384);
         ZK_HIP(hipHostGetDevicePointer(&s->mbox_dev, s->mbox, 0));
     }
     *host = s->mbox;
@@ -538,7 +538,7 @@ int zk_mle_evaluate(const zk_table *t, const uint64_t *values, size_t nvalues, u
             cur = dst;
             break;
         }
-        size_t k = nvalues - i < (size_t)kMultiMax ? nvalues - i : (size_t)kMultiMax;
+        size_t k = nvalues - i < (size_t)kEvalMultiMax ? nvalues - i : (size_t)kEvalMultiMax;
         while (k > 1 && (cur->len >> k) < 2 * (size_t)kEvalTailBlock) k--;                       // leave the tail its share
         if (vdev.p && k >= 2 && cur->len >= kMultiFrom) {
             const void *rp[kMultiMax];

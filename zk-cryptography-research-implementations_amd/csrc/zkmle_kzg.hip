@@ -178,7 +178,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     // at 2^20 terms: 4.13 / 3.59 / 3.50 / 3.81.  ZK_MSM_SEG_SHIFT / ZK_MSM_SEG_MIN override, for measurements.
     static const int seg_shift = [] { const char *e = getenv("ZK_MSM_SEG_SHIFT"); int k = e ? atoi(e) : 22; return k < 10 ? 10 : (k > 24 ? 24 : k); }();
     size_t seg_target = ((size_t)n * nwin1) >> seg_shift;
-    static const unsigned seg_min = [] { const char *e = getenv("ZK_MSM_SEG_MIN"); int k = e ? atoi(e) : 16; return (unsigned)(k < 2 ? 2 : k); }();
+    static const unsigned seg_min = [] { const char *e = getenv("ZK_MSM_SEG_MIN"); int k = e ? atoi(e) : 32; return (unsigned)(k < 2 ? 2 : k); }();   // r3, balanced runs, 2^20 terms (bucket phase, ms; 16 / 32 / 64): 2.97 / 2.86 / 2.86
     unsigned seg_len = (unsigned)(seg_target < seg_min ? seg_min : seg_target);
     // the batched pass feeds a bucket from every window: the largest level's buckets hold ~16 * 2^19 / 2^15 = 256 entries, and
     // 16-entry segments would put them just over the 16-partials-per-bucket limit of the combine kernel (an extra 1.3 ms regroup)

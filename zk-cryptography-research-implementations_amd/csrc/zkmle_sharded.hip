@@ -403,9 +403,9 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
         // basic sumcheck, several rounds per pass and per all-reduce (basic_multi.cuh): the top-bit segments of the global table are
         // the top-bit segments of every rank's shard, so the 2^m segment sums add up over the ranks like the two half sums do
         const size_t W = (size_t)field_limbs64(field) * 2 + 1;
-        auto pass = [&](size_t global_len) {
-            const unsigned left = (unsigned)(ilog2(global_len) - ilog2(kTail));
-            return left < kmax ? left : kmax;
+        auto pass = [&](size_t global_len) {                               // the rounds left, spread evenly over the passes they need
+            const unsigned left = (unsigned)(ilog2(global_len) - ilog2(kTail)), passes = (left + kmax - 1) / kmax;
+            return (left + passes - 1) / passes;
         };
         const zk_table *one = tabs[0];
         if (L * G > kTail) {

@@ -198,7 +198,7 @@ template <class F> struct DeviceRounds {
             // (collect); anything else on this thread's stream -- a proof that failed, other work -- is waited for
             if (!g_last_proof_clean) ZK_HIP(stream_wait_idle());
             g_last_proof_clean = false;
-            memset((void *)mb, 0, sizeof(HostMailbox));
+            memset((void *)mb, 0, offsetof(HostMailbox, big));
             htr = &tr;
             hs.assign(nslots, fe_zero<F>());
             hbasis = basis_flat;
@@ -286,7 +286,7 @@ template <class F> struct DeviceRounds {
         const size_t per = q.s[0];
         size_t n = (size_t)1 << m;
         Fe<F> S[1 << kMultiMax];
-        for (size_t t = 0; t < n; t++) S[t] = mb_get(mb->fin + 12 * t);
+        for (size_t t = 0; t < n; t++) S[t] = mb_get(mb->big + 12 * t);
         for (int i = 0; i < m; i++) {
             const size_t half = n / 2;
             Fe<F> a0 = S[0], a1 = S[half];                                     // prover.rs:50 (split_polynomial_and_sum_each :74-89)
@@ -301,13 +301,13 @@ template <class F> struct DeviceRounds {
             const Fe<F> r = htr->template random_challenge_as_field_element<F>();   // :58
             hs[q.chal_slot + per * i] = r;
             running_claim = fe_add<F>(a0, fe_mul<F>(r, fe_sub<F>(a1, a0)));
-            for (int k = 0; k < F::N; k++) __atomic_store_n(&mb->ans4[i][1 + k], r.l[k], __ATOMIC_RELAXED);
+            for (int k = 0; k < F::N; k++) __atomic_store_n(&mb->ans8[i][1 + k], r.l[k], __ATOMIC_RELAXED);
             for (size_t j = 0; j < half; j++) S[j] = fe_add<F>(S[j], fe_mul<F>(r, fe_sub<F>(S[half + j], S[j])));   // :61-63
             n = half;
         }
         for (int i = 0; i < m; i++) {                                          // the answer lines' tags last (dev_transcript.cuh)
-            __atomic_store_n(&mb->ans4[i][0], (uint32_t)seq, __ATOMIC_RELEASE);
-            __atomic_store_n(&mb->ans4[i][15], (uint32_t)seq, __ATOMIC_RELEASE);
+            __atomic_store_n(&mb->ans8[i][0], (uint32_t)seq, __ATOMIC_RELEASE);
+            __atomic_store_n(&mb->ans8[i][15], (uint32_t)seq, __ATOMIC_RELEASE);
         }
     }
     void serve_link(const Req &q) {                                            // gkr_protocol.rs:125-132
@@ -415,13 +415,13 @@ template <class F> struct DeviceRounds {
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
-    // host mode, basic sumcheck (basic_multi.cuh): rounds round .. round + m - 1 from 2^m segment sums, given as partial lists
-    // (partials[seg * count + i]) or as all-reduced limbs; slots of round k: 1 + 3 k, 2 + 3 k (sums), 3 + 3 k (challenge), claim 0
-    int launch_multi(const void *partials, size_t count, const uint64_t *limbs_in, int m, size_t round) {
-        if (!host_mode || m < 1 || m > kMultiMax) return ZK_E_ARG;
+    // host mode, basic sumcheck (basic_multi.cuh): rounds round .. round + m - 1 from the 2^m segment sums an all-reduce has left as limb
+    // words (sharded table); slots of round k: 1 + 3 k, 2 + 3 k (sums), 3 + 3 k (challenge), claim 0
+    int launch_multi(const uint64_t *limbs_in, int m, size_t round) {
+        if (!host_mode || !limbs_in || m < 1 || m > kMultiMax) return ZK_E_ARG;
         push_req(Req{kMulti, 0, m, round == 0 ? 1 : 0, 0, 0, 0, 1 + 3 * round, 3 + 3 * round, 0, {3, 0, 0, 0, 0, 0, 0}});
-        MultiArgs a{partials, count, limbs_in, nullptr, m, mb_dev, (uint64_t)nreq(), proof(), 3 + 3 * round, 3};
-        multi_finish_kernel<F><<<1, 64 << m, 0, cur_stream()>>>(a);
+        MultiArgs a{limbs_in, m, mb_dev, (uint64_t)nreq(), proof(), 3 + 3 * round, 3};
+        multi_finish_kernel<F><<<1, 64, 0, cur_stream()>>>(a);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
@@ -440,21 +440,13 @@ template <class F> struct DeviceRounds {
         return ZK_OK;
     }
     MultiFin multi_fin_limbs(int m, uint64_t *limbs_out) const { return MultiFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), m, limbs_out, nullptr, 0, nullptr, 0, 0, nullptr}; }
-    // the 2^m segment sums as limbs for the all-reduce of a sharded table (nothing posted)
-    int launch_multi_limbs(const void *partials, size_t count, int m, uint64_t *limbs_out) {
-        if (m < 1 || m > kMultiMax) return ZK_E_ARG;
-        MultiArgs a{partials, count, nullptr, limbs_out, m, nullptr, 0, nullptr, 0, 0};
-        multi_finish_kernel<F><<<1, 64 << m, 0, cur_stream()>>>(a);
-        ZK_HIP(hipGetLastError());
-        return ZK_OK;
-    }
     // host mode, basic sumcheck: every round of a table of <= kTailLen entries (rounds round ..), one launch (basic_multi.cuh)
     int launch_basic_tail(const void *in, void *buf, size_t len, size_t round) {
         if (!host_mode || len < 2 || len > kTailLen) return ZK_E_ARG;
         BasicTailArgs a{in, buf, len, mb_dev, (uint64_t)nreq() + 1, proof(), 3 + 3 * round, 3};
         size_t rd = round;
         for (size_t cl = len; cl >= 2;) {
-            const int lg = (int)ilog2(cl), m = lg < kMultiMax ? lg : kMultiMax;
+            const int lg = (int)ilog2(cl), m = lg < kTailMultiMax ? lg : kTailMultiMax;
             push_req(Req{kMulti, 0, m, rd == 0 ? 1 : 0, 0, 0, 0, 1 + 3 * rd, 3 + 3 * rd, 0, {3, 0, 0, 0, 0, 0, 0}});
             rd += (size_t)m;
             cl >>= m;
@@ -569,18 +561,22 @@ template <class F> struct DeviceRounds {
 };
 
 // ---- several rounds per pass (basic_multi.cuh) -------------------------------------------------------
-static int multi_kmax() {                                  // ZK_BASIC_ROUNDS_PER_PASS = 1..4 (default 4): for measurements
+static int multi_kmax() {                                  // ZK_BASIC_ROUNDS_PER_PASS = 1..8: for measurements (default 7)
     static const int v = [] {
         const char *e = getenv("ZK_BASIC_ROUNDS_PER_PASS");
-        int k = e ? atoi(e) : kMultiMax;
+        int k = e ? atoi(e) : 7;
         return k < 1 ? 1 : k > kMultiMax ? kMultiMax : k;
     }();
     return v;
 }
-// rounds of the next pass over a table of `global_len` entries (> kTailLen): never past the length the tail takes over at
+// rounds of the next pass over a table of `global_len` entries (> kTailLen): never past the length the tail takes over at, and the rounds
+// left are spread evenly over the passes they need (13 rounds = 7 + 6 rather than 8 + 5: the host's share of an exchange grows with 2^m,
+// and the fold of 8 variables reads 256 streams per lane -- r3 sweep at 2^24 / 2^20, ms per proof: m <= 4 0.338 / 0.123, 5 0.346 / 0.120,
+// 6 0.330 / 0.121, 7 0.332 / 0.137 (7 + 2), 8 0.348 / 0.191)
 static int multi_pass_rounds(size_t global_len) {
-    const int left = (int)ilog2(global_len) - (int)ilog2(kTailLen);
-    return left < multi_kmax() ? left : multi_kmax();
+    const int left = (int)ilog2(global_len) - (int)ilog2(kTailLen), kmax = multi_kmax();
+    const int passes = (left + kmax - 1) / kmax;
+    return (left + passes - 1) / passes;
 }
 template <class F> int launch_seg_sums(const void *in, size_t len, int m, void *part, unsigned *bps_out, const MultiFin *fin = nullptr) {
     const size_t seglen = len >> m;
@@ -590,6 +586,20 @@ template <class F> int launch_seg_sums(const void *in, size_t len, int m, void *
     *bps_out = bps;
     return ZK_OK;
 }
+// One pass that folds k variables (challenges at rp[0 .. k)) of `in` (n << k entries) into `out` (n entries).  A pass that leaves no
+// segment sums and a SHORT output (the last one before the tail: 2^11 entries from 2^17) would run on n / 256 workgroups, each lane reading
+// 2^k inputs one chunk after the other -- 34 us for 4 MB (r3 trace); it goes as two passes of about k / 2 variables through `tmp`
+// (>= n << (k - k / 2) entries), 64 and 8 workgroups with 8 loads per lane each.
+template <class F>
+int fold_pass(const void *in, void *out, void *tmp, size_t n, int k, const void *const *rp, int m_next, void *part, unsigned *bps, const MultiFin *fin) {
+    if (m_next == 0 && k >= 4 && n <= ((size_t)1 << 13) && tmp) {
+        const int k1 = k / 2;
+        ZK_TRY((launch_foldk<F, true>(in, tmp, n << (k - k1), k1, rp, 0, part, bps, nullptr)));
+        return launch_foldk<F, true>(tmp, out, n, k - k1, rp + k1, 0, part, bps, nullptr);
+    }
+    return launch_foldk<F, true>(in, out, n, k, rp, m_next, part, bps, fin);
+}
+
 // ---- basic sumcheck prover: prover.rs:22-71 ----------------------------------------------------------
 template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys, uint64_t *challenges) {
     const size_t esz = 4 * F::N, L64 = F::N / 2;
@@ -601,7 +611,7 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
     double t1 = now_ms();
     g_stats = zk_sumcheck_stats{nvars, (float)(t1 - t0), 0.f};
     // working buffers: len/2 and len/4 elements, plus reduction partials
-    DevBuf bufA, bufB;
+    DevBuf bufA, bufB, bufT;
     ZK_TRY(bufA.alloc((len / 2) * esz));
     ZK_TRY(bufB.alloc((len / 4) * esz));
     void *part;
@@ -634,7 +644,13 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
                 const void *rp[kMultiMax];
                 for (int i = 0; i < m; i++) rp[i] = dr.slot_ptr(3 + 3 * (round + (size_t)i));
                 if (mn) ZK_TRY(dr.multi_fin(mn, round + (size_t)m, &fin));
-                ZK_TRY((launch_foldk<F, true>(cur, dst, n, m, rp, mn, part, &bps, mn ? &fin : nullptr)));   // :61-63 m times, fused with :74-89 and the exchange of the next rounds
+                // :61-63 m times, fused with :74-89 and the exchange of the next rounds
+                void *tmp = nullptr;
+                if (mn == 0 && m >= 4 && n <= ((size_t)1 << 13)) {              // fold_pass splits a short last pass in two
+                    ZK_TRY(bufT.alloc((n << (m - m / 2)) * esz));
+                    tmp = bufT.p;
+                }
+                ZK_TRY((fold_pass<F>(cur, dst, tmp, n, m, rp, mn, part, &bps, mn ? &fin : nullptr)));
                 cur = dst;
                 void *nx = other;
                 other = dst;
@@ -753,9 +769,10 @@ int check_sumpoly_cf(const zk_table *const *tables, size_t nprod, size_t nfac, c
 
 // skip1: the two-factor lazy kernel leaves out the products of the point 1 (the caller derives e(1) = claim - e(0)); others ignore it
 template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t half, void *part, int grid, int skip1 = 0) {
-    if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, 0);
-    else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, skip1);
-    else round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, 0);
+    if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
+    else if (nfac == 2 && skip1 && LazyProducts<F>::value) round_evals_kernel<F, 2, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
+    else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
+    else round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -770,9 +787,13 @@ template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int np
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
-    if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
-    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
-    else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, skip1);
+    if (skip1) {
+        if (nfac == 1) fold_round_evals_kernel<F, 1, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
+        else if (nfac == 2) fold_round_evals_kernel<F, 2, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
+        else fold_round_evals_kernel<F, 3, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
+    } else if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
+    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
+    else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -971,7 +992,7 @@ template <class F> struct RoundsImpl : RoundsBase {
     bool tail_done = false;
     bool skipped1 = false;                               // the limbs on their way lack the point 1 (derived in absorb)
     DeviceRounds<F> dr;
-    DevBuf tailbuf;
+    DevBuf tailbuf, foldtmp;
 
     int init(int mode_, size_t nprod_, size_t nfac_, size_t nrounds_, Transcript &tr) {
         mode = mode_; nprod = nprod_; nfac = nfac_; ntab = nprod * nfac; npts = nfac + 1; nrounds = nrounds_;
@@ -1088,7 +1109,7 @@ template <class F> struct RoundsImpl : RoundsBase {
     }
     int multi_absorb(const uint64_t *limbs, unsigned m) override {
         if (!limbs || m < 1 || m > multi_max() || round + m > nrounds) return ZK_E_ARG;
-        ZK_TRY(dr.launch_multi(nullptr, 0, limbs, (int)m, round));
+        ZK_TRY(dr.launch_multi(limbs, (int)m, round));
         round += m;
         return ZK_OK;
     }
@@ -1105,7 +1126,12 @@ template <class F> struct RoundsImpl : RoundsBase {
         unsigned bps;
         MultiFin fin = dr.multi_fin_limbs((int)m_next, limbs);
         if (m_next && !limbs) ZK_TRY(dr.multi_fin((int)m_next, round, &fin));
-        ZK_TRY((launch_foldk<F, true>(in->dptr, out->dptr, n, (int)k, rp, (int)m_next, part, &bps, m_next ? &fin : nullptr)));
+        void *tmp = nullptr;
+        if (m_next == 0 && k >= 4 && n <= ((size_t)1 << 13)) {                    // fold_pass splits a short last pass in two
+            ZK_TRY(foldtmp.alloc((n << (k - k / 2)) * 4 * F::N));
+            tmp = foldtmp.p;
+        }
+        ZK_TRY((fold_pass<F>(in->dptr, out->dptr, tmp, n, (int)k, rp, (int)m_next, part, &bps, m_next ? &fin : nullptr)));
         out->len = n;
         if (m_next && !limbs) round += m_next;
         return ZK_OK;
