@@ -265,6 +265,61 @@ template <class F> __device__ __forceinline__ Fe<F> mailbox_element(const uint32
 
 constexpr int kMaxPts = kMaxFactors + 1;
 
+// The round's exchange in the producer's last workgroup (sumcheck_kernels.cuh RoundFin): wave 0 of every workgroup, lane t < npts holding
+// the workgroup's sum of evaluation t.
+template <class F> __device__ __forceinline__ void round_finish_in_producer(const RoundFin &f, const Fe<F> &tot) {
+    const unsigned lane = threadIdx.x & 63u;
+    const bool mine = (int)lane < f.npts && !(f.skip1 && lane == 1u);
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(f.acc) + (size_t)lane * F::N * kMultiAccStride;
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < F::N; k++)
+            __hip_atomic_fetch_add(acc + (size_t)k * kMultiAccStride, (unsigned long long)tot.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned last = 0;
+    if (lane == 0) {
+        const unsigned g = blockIdx.x / f.group, ngroups = (gridDim.x + f.group - 1) / f.group;
+        const unsigned members = (g + 1) * f.group <= gridDim.x ? f.group : gridDim.x - g * f.group;
+        unsigned *gc = f.counter + 16u * (1u + g);
+        if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+            __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u) {
+                __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1u;
+            }
+        }
+    }
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
+    Fe<F> e = fe_zero<F>();
+    if (mine) {
+        unsigned long long v[F::N + 1];
+#pragma unroll
+        for (int k = 0; k < F::N; k++) v[k] = __hip_atomic_load(acc + (size_t)k * kMultiAccStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[F::N] = 0;
+#pragma unroll
+        for (int k = 0; k < F::N; k++) __hip_atomic_store(acc + (size_t)k * kMultiAccStride, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Wide<F> w;
+        unsigned long long c = 0;
+#pragma unroll
+        for (int k = 0; k <= F::N; k++) {
+            const unsigned long long x = v[k] + c;
+            w.l[k] = (uint32_t)x;
+            c = x >> 32;
+        }
+        e = wide_reduce<F>(w);
+    }
+    if ((int)lane < f.npts) {                                // the evaluations, as mailbox_post lays them out
+#pragma unroll
+        for (int k = 0; k < F::N; k++) f.mb->ev[lane * 12 + k] = e.l[k];
+    }
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __atomic_store_n(&f.mb->gpu_seq, f.seq, __ATOMIC_RELEASE);
+    const Fe<F> r = mailbox_wait_challenge<F>(f.mb, f.seq, lane);
+    if (lane == 0) fe_store<F>(f.proof, f.chal_slot, r);
+}
+
 // what a round's transcript step needs besides the evaluations
 struct RoundCtx {
     int npts;                // evaluations per round (2 = basic sumcheck halves, d + 1 for the GKR sumcheck)

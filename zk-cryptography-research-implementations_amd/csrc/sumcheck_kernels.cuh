@@ -27,6 +27,25 @@ struct SumPolyTables {
     const void *cptr[kMaxProducts];                // non-null: the constant is read from device memory instead (one element; a value an
                                                    // earlier kernel of the same stream produced, e.g. u = W(rb*) of the sparse GKR prover)
 };
+// The round's exchange run by the LAST workgroup of the kernel that produces the round's evaluations (host-assisted transcript step only;
+// dev_transcript.cuh round_finish_in_producer; null counter: the workgroups leave partials for a finish kernel instead).  Same scheme as the
+// basic sumcheck's passes (basic_multi.cuh): every workgroup adds its sums to accumulator words on lines of their own with device-scope
+// atomics and arrives at a two-level counter; the last one reads the npts sums, posts them and waits for the challenge.
+struct HostMailbox;
+struct RoundFin {
+    unsigned *counter;       // the kernel's arrival counter, then one per group of `group` workgroups, 16 words apart; zero before the launch and left zero
+    uint64_t *acc;           // npts x N words, kMultiAccStride words apart, zero before the launch and left zero
+    int npts;                // evaluations per round
+    int skip1;               // the point 1 is not evaluated: its words are neither written nor read (the host derives it)
+    unsigned group;          // workgroups per arrival group
+    HostMailbox *mb;
+    uint64_t seq;
+    void *proof;
+    size_t chal_slot;
+};
+// wave 0 of every workgroup calls this; lane t < npts holds the workgroup's sum of evaluation t in `tot` (stored form, fully reduced)
+template <class F> __device__ __forceinline__ void round_finish_in_producer(const RoundFin &f, const Fe<F> &tot);   // dev_transcript.cuh
+
 // A product whose second factor is a constant c is a linear term: sum_i c X(i).  Its table is never materialised, loaded, folded or
 // stored (a constant folds to itself); the evaluation products use c directly.  The sparse GKR prover's phases are
 // W H1 + H0 * 1 and C W + A * u (zkmle_gkr_sparse.hip): three streamed tables instead of four.
@@ -193,7 +212,7 @@ template <class F> __device__ __forceinline__ Fe<F> prodwide_reduce(const ProdWi
 }
 // workgroup totals of the lazily accumulated products -> partials, same layout as write_partials
 template <class F, bool SKIP1>
-__device__ __forceinline__ void write_partials_lazy(ProdAcc<F> (&acc)[SKIP1 ? 2 : 3], ProdWide<F> *sh, void *partials) {
+__device__ __forceinline__ void write_partials_lazy(ProdAcc<F> (&acc)[SKIP1 ? 2 : 3], ProdWide<F> *sh, void *partials, const RoundFin &fin) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     constexpr int skip1 = SKIP1 ? 1 : 0;
 #pragma unroll
@@ -211,25 +230,29 @@ __device__ __forceinline__ void write_partials_lazy(ProdAcc<F> (&acc)[SKIP1 ? 2 
         if (lane == 63) sh[k * nw + wave] = v;
     }
     __syncthreads();
-    if ((int)threadIdx.x >= 3) return;
+    if ((int)threadIdx.x >= (fin.counter ? 64 : 3)) return;
     Fe<F> tot = fe_zero<F>();
-    if (!(threadIdx.x == 1 && skip1)) {
+    if (threadIdx.x < 3 && !(threadIdx.x == 1 && skip1)) {
         ProdWide<F> t = sh[threadIdx.x * nw];
         for (int w = 1; w < nw; w++) prodwide_add<F>(t, sh[threadIdx.x * nw + w]);
         tot = prodwide_reduce<F>(t);
     }
-    fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
+    if (fin.counter) round_finish_in_producer<F>(fin, tot);
+    else fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
 }
 
 template <class F, int NFAC>
-__device__ __forceinline__ void write_partials(Wide<F> (&acc)[NFAC + 1], Wide<F> *sh, void *partials) {
-    Fe<F> tot;
-    if (block_reduce_wide<F, NFAC + 1>(acc, sh, tot)) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
+__device__ __forceinline__ void write_partials(Wide<F> (&acc)[NFAC + 1], Wide<F> *sh, void *partials, const RoundFin &fin) {
+    Fe<F> tot = fe_zero<F>();
+    const bool have = block_reduce_wide<F, NFAC + 1>(acc, sh, tot);
+    if (fin.counter) {
+        if (threadIdx.x < 64) round_finish_in_producer<F>(fin, tot);
+    } else if (have) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
 }
 
 // tables of `2 * half` entries; partials[t * gridDim.x + block]
 template <class F, int NFAC, bool SKIP1 = false>
-__global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials) {
+__global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials, RoundFin fin) {
     if constexpr (NFAC == 2 && LazyProducts<F>::value) {
         __shared__ ProdWide<F> shp[3 * kBlock / 64];
         constexpr int NACC = SKIP1 ? 2 : 3;
@@ -255,7 +278,7 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
                 }
             }
         }
-        write_partials_lazy<F, SKIP1>(pacc, shp, partials);
+        write_partials_lazy<F, SKIP1>(pacc, shp, partials, fin);
         return;
     }
     __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];
@@ -277,14 +300,14 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
             accumulate_terms<F, NFAC>(lo, hi, acc);
         }
     }
-    write_partials<F, NFAC>(acc, sh, partials);
+    write_partials<F, NFAC>(acc, sh, partials, fin);
 }
 
 // tables of 4q entries in, 2q out; lane i folds outputs i and i+q of every table, then uses them
 // as the (lo, hi) pair of the NEXT round.
 template <class F, int NFAC, bool SKIP1>
 __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs, int nprod, size_t q, const Fe<F> &r, void *__restrict__ partials,
-                                                      const void *__restrict__ rp) {
+                                                      const void *__restrict__ rp, const RoundFin &fin) {
     constexpr int skip1 = SKIP1 ? 1 : 0;
     if constexpr (NFAC == 2 && LazyProducts<F>::value) {
         __shared__ ProdWide<F> shp[3 * kBlock / 64];
@@ -318,7 +341,7 @@ __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs,
                 }
             }
         }
-        write_partials_lazy<F, SKIP1>(pacc, shp, partials);
+        write_partials_lazy<F, SKIP1>(pacc, shp, partials, fin);
         return;
     }
     __shared__ Wide<F> sh[(NFAC + 1) * kBlock / 64];
@@ -345,12 +368,12 @@ __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs,
             accumulate_terms<F, NFAC>(lo, hi, acc, skip1);
         }
     }
-    write_partials<F, NFAC>(acc, sh, partials);
+    write_partials<F, NFAC>(acc, sh, partials, fin);
 }
 template <class F, int NFAC, bool SKIP1 = false>
 __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials,
-                                                                  const void *__restrict__ rp = nullptr) {
-    fold_round_evals_body<F, NFAC, SKIP1>(tabs, nprod, q, r, partials, rp);
+                                                                  const void *__restrict__ rp, RoundFin fin) {
+    fold_round_evals_body<F, NFAC, SKIP1>(tabs, nprod, q, r, partials, rp, fin);
 }
 // The same round for SHORT tables of products of two factors.  Below ~2^15 pair indices the launch above does not fill the
 // device and lasts as long as one lane's chain of products (14 for two products); here a wave takes ONE table for 64 consecutive
@@ -359,7 +382,7 @@ __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables 
 constexpr size_t kSplitRoundMaxQ = (size_t)1 << 15;
 template <class F>
 __global__ void __launch_bounds__(512) fold_round_evals_split_kernel(SumPolyTables tabs, size_t q, Fe<F> r, void *__restrict__ partials,
-                                                                     const void *__restrict__ rp, int skip1) {
+                                                                     const void *__restrict__ rp, int skip1, RoundFin fin) {
     __shared__ Fe<F> exch[2 * 64 * 8];
     __shared__ Wide<F> sh[3 * 8];
     const unsigned k = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -389,8 +412,11 @@ __global__ void __launch_bounds__(512) fold_round_evals_split_kernel(SumPolyTabl
     } else if (!skip1) {
         wide_add_fe<F>(acc[1], fe_mul<F>(hi, hi2));
     }
-    Fe<F> tot;
-    if (block_reduce_wide<F, 3>(acc, sh, tot)) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
+    Fe<F> tot = fe_zero<F>();
+    const bool have = block_reduce_wide<F, 3>(acc, sh, tot);
+    if (fin.counter) {
+        if (threadIdx.x < 64) round_finish_in_producer<F>(fin, tot);
+    } else if (have) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
 }
 
 // element-wise reduce of a SumPolynomial to one table: out[i] = sum_p prod_f X[p][f][i]

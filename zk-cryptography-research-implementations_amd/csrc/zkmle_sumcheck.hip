@@ -415,6 +415,18 @@ template <class F> struct DeviceRounds {
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
+    // host mode: the round's exchange runs in the last workgroup of the kernel that produces its evaluations (sumcheck_kernels.cuh RoundFin,
+    // dev_transcript.cuh round_finish_in_producer) instead of in a finish kernel: registers the request, hands back what that launch needs.
+    // `grid` = the producer's workgroups.
+    int round_fin(int grid, int npts, int mode, int with_claim, size_t claim_slot, size_t msg_slot, size_t chal_slot, int derive_prev, RoundFin *out) {
+        if (!host_mode) return ZK_E_ARG;
+        push_req(Req{kRound, mode, npts, with_claim, derive_prev, 0, claim_slot, msg_slot, chal_slot, 0, {0, 0, 0, 0, 0, 0, 0}});
+        unsigned group = 32;
+        while ((unsigned)(grid + group - 1) / group > 200u) group *= 2;   // one 64-byte counter slot per group (context.h kSyncCounterBytes)
+        *out = RoundFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), npts, derive_prev, group, mb_dev, (uint64_t)nreq(), proof(),
+                        chal_slot};
+        return ZK_OK;
+    }
     // host mode, basic sumcheck (basic_multi.cuh): rounds round .. round + m - 1 from the 2^m segment sums an all-reduce has left as limb
     // words (sharded table); slots of round k: 1 + 3 k, 2 + 3 k (sums), 3 + 3 k (challenge), claim 0
     int launch_multi(const uint64_t *limbs_in, int m, size_t round) {
@@ -767,33 +779,41 @@ int check_sumpoly_cf(const zk_table *const *tables, size_t nprod, size_t nfac, c
     return ZK_OK;
 }
 
-// skip1: the two-factor lazy kernel leaves out the products of the point 1 (the caller derives e(1) = claim - e(0)); others ignore it
-template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t half, void *part, int grid, int skip1 = 0) {
-    if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
-    else if (nfac == 2 && skip1 && LazyProducts<F>::value) round_evals_kernel<F, 2, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
-    else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
-    else round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part);
+// skip1: the two-factor lazy kernel leaves out the products of the point 1 (the caller derives e(1) = claim - e(0)); others ignore it.
+// fin (host-assisted transcript step): the launch's last workgroup runs the round's exchange, nothing is left in `part`.
+template <class F> int launch_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t half, void *part, int grid, int skip1 = 0,
+                                          const RoundFin *fin = nullptr) {
+    const RoundFin f = fin ? *fin : RoundFin{};
+    if (nfac == 1) round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, f);
+    else if (nfac == 2 && skip1 && LazyProducts<F>::value) round_evals_kernel<F, 2, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, f);
+    else if (nfac == 2) round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, f);
+    else round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, half, part, f);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
+}
+// the grid the fused round will be launched with (`grid` = reduce_grid_for(q) on entry), before the launch: the split kernel has its own
+inline bool fold_round_takes_split(int nprod, int nfac, size_t q, bool may_split) {
+    static const size_t split_max_q = [] { const char *e = getenv("ZK_SPLIT_ROUND_BITS"); int b = e ? atoi(e) : 0; return b >= 6 && b <= 24 ? (size_t)1 << b : kSplitRoundMaxQ; }();
+    return may_split && nfac == 2 && nprod >= 2 && nprod <= 4 && q >= 64 && q <= split_max_q;
 }
 // `grid` = the number of partials written per evaluation point.  With `may_split` the caller lets short rounds of two-factor
 // products take the split kernel, which changes `grid` (sumcheck_kernels.cuh).
 template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t q, const Fe<F> &r, void *part, int &grid,
-                                               const void *rp = nullptr, int skip1 = 0, bool may_split = false) {
-    static const size_t split_max_q = [] { const char *e = getenv("ZK_SPLIT_ROUND_BITS"); int b = e ? atoi(e) : 0; return b >= 6 && b <= 24 ? (size_t)1 << b : kSplitRoundMaxQ; }();
-    if (may_split && nfac == 2 && nprod >= 2 && nprod <= 4 && q >= 64 && q <= split_max_q) {
+                                               const void *rp = nullptr, int skip1 = 0, bool may_split = false, const RoundFin *fin = nullptr) {
+    const RoundFin f = fin ? *fin : RoundFin{};
+    if (fold_round_takes_split(nprod, nfac, q, may_split)) {
         grid = (int)(q / 64);
-        fold_round_evals_split_kernel<F><<<grid, 64 * 2 * nprod, 0, cur_stream()>>>(tabs, q, r, part, rp, skip1);
+        fold_round_evals_split_kernel<F><<<grid, 64 * 2 * nprod, 0, cur_stream()>>>(tabs, q, r, part, rp, skip1, f);
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
     if (skip1) {
-        if (nfac == 1) fold_round_evals_kernel<F, 1, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
-        else if (nfac == 2) fold_round_evals_kernel<F, 2, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
-        else fold_round_evals_kernel<F, 3, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
-    } else if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
-    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
-    else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp);
+        if (nfac == 1) fold_round_evals_kernel<F, 1, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
+        else if (nfac == 2) fold_round_evals_kernel<F, 2, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
+        else fold_round_evals_kernel<F, 3, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
+    } else if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
+    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
+    else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -874,8 +894,14 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
         int grid = reduce_grid_for(half);
         // host-assisted step only: the host keeps the running claim (the device variant reads the previous round's slots, which round 0 has not)
         const int skip0 = (own_claim && dr.host_mode && nfac == 2 && LazyProducts<F>::value && half >= ((size_t)1 << 14)) ? 1 : 0;
-        ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid, skip0)));
-        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, with_claim, claim_slot, s0, s0 + npts, skip0, per));
+        if (dr.host_mode) {                                            // the exchange runs in the kernel's last workgroup
+            RoundFin fin;
+            ZK_TRY(dr.round_fin(grid, (int)npts, 1, with_claim, claim_slot, s0, s0 + npts, skip0, &fin));
+            ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid, skip0, &fin)));
+        } else {
+            ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid, skip0)));
+            ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, with_claim, claim_slot, s0, s0 + npts, skip0, per));
+        }
     }
     char *dst = (char *)bufA.p, *other = (char *)bufB.p;
     size_t cl = len;
@@ -892,8 +918,15 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
         // (dev_transcript.cuh kDerive1).  Below ~2^14 pair indices the helper wave's two products take longer than the
         // reduction they hide behind, so small rounds evaluate the point 1 directly (measured r1: 4 x 2^22 1.28 -> 1.23 ms).
         const int skip1 = q >= ((size_t)1 << 14) ? 1 : 0;
-        ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true)));
-        ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, s0 + per * (round + 1), s0 + per * (round + 1) + npts, skip1, per));
+        if (dr.host_mode) {
+            RoundFin fin;
+            const int g = fold_round_takes_split((int)nprod, (int)nfac, q, true) ? (int)(q / 64) : grid;
+            ZK_TRY(dr.round_fin(g, (int)npts, 1, 0, 0, s0 + per * (round + 1), s0 + per * (round + 1) + npts, skip1, &fin));
+            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true, &fin)));
+        } else {
+            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true)));
+            ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, s0 + per * (round + 1), s0 + per * (round + 1) + npts, skip1, per));
+        }
         for (size_t k = 0; k < ntab; k++) tabs.in[k] = tabs.out[k];
         char *nx = other;
         other = dst;
