@@ -487,7 +487,7 @@ def config5_leg(zk, env, args):
         cur /= 2 ** m
         left -= m
     out["sumcheck"] = {"what": f"Prover::prove rounds of the 2^{args.log_n} table ({rp.shape[0]} rounds), 2^{args.log_n}/{world} entries per rank, "
-                               "up to 4 rounds per pass over the shard: one all-reduce(SUM) of 2^m x 9 int64 words (m <= 4 rounds' segment sums) on the prover's stream per pass, replicated one-launch tail, transcript steps on each rank's host through the mailbox",
+                               "up to 7 rounds per pass over the shard (13 = 7 + 6): one all-reduce(SUM) of 2^m x 9 int64 words (the segment sums that carry the pass's m rounds) on the prover's stream per pass -- at one rank the pass's last workgroup runs the exchange itself --, replicated one-launch tail, transcript steps on each rank's host through the mailbox",
                        "ms_per_proof": dt * 1e3, "field_mul_per_s": (n_global - 1) / dt, "rounds": int(rp.shape[0]),
                        "collectives_per_proof": (nc1 - nc0) // 5, "bytes_received_per_proof": (rx1 - rx0) // 5,
                        "hbm_GBps_whole_proof": traffic / dt / 1e9, "frac_of_hbm_peak_whole_proof": traffic / dt / 1e9 / (HBM_PEAK_GBPS * world),
@@ -591,10 +591,11 @@ def msm_leg(zk, env, args, shared=None):
            "workload": f"2^{args.log_n} random Fr scalars x synthetic affine bases [a + i d]G per GPU; one Pippenger per rank, all-gather of {world} points"}
     if check is not None:
         res["post_check"] = check
-    try:
-        res["roofline"] = msm_roofline(st)
-    except Exception as e:                                  # noqa: BLE001
-        res["roofline"] = {"error": repr(e)}
+    if rank == 0:                                           # (one micro-benchmark child process per job, not per rank)
+        try:
+            res["roofline"] = msm_roofline(st)
+        except Exception as e:                              # noqa: BLE001
+            res["roofline"] = {"error": repr(e)}
     if shared is not None and shared.get("pre"):
         res["precomputed_bases"] = dict(shared["pre"], device_ms={k: shared["pre_st"][k] for k in ("ms_digits", "ms_sort", "ms_buckets", "ms_reduce", "ms_total")})
         try:
@@ -623,12 +624,14 @@ def msm_roofline(st):
 
 
 _MAD_PEAK = None
+_MAD_LOCK = threading.Lock()
 
 
 def measured_mad_peak():
     global _MAD_PEAK
-    if _MAD_PEAK is None:
-        _MAD_PEAK = _measure_mad_peak()
+    with _MAD_LOCK:
+        if _MAD_PEAK is None:
+            _MAD_PEAK = _measure_mad_peak()
     return _MAD_PEAK
 
 
