@@ -73,6 +73,13 @@ pub mod ffi {
         pub fn zk_comm_unique_id(out128: *mut u8) -> c_int;
         pub fn zk_comm_init_rccl(id128: *const u8, nranks: c_int, rank: c_int, out: *mut *mut c_void) -> c_int;
         pub fn zk_comm_free(c: *mut c_void) -> c_int;
+        // the ranks as threads of this process (one thread per GPU): include/zkmle.h zk_comm_local_group_*
+        pub fn zk_comm_local_group_new(nranks: c_int, out: *mut *mut c_void) -> c_int;
+        pub fn zk_comm_local_group_free(g: *mut c_void) -> c_int;
+        pub fn zk_comm_local_group_abort(g: *mut c_void) -> c_int;
+        pub fn zk_comm_from_local_group(g: *mut c_void, rank: c_int, out: *mut *mut c_void) -> c_int;
+        // once per TrustedSetup: window-shifted copies of g1_powers_of_tau, so that every later commit uses one bucket set (22-bit windows)
+        pub fn zk_g1_bases_precompute(b: *mut zk_g1_bases, window_bits: c_int) -> c_int;
         pub fn zk_sharded_sumcheck_basic_prove(c: *mut c_void, shard: *const zk_table, absorb_table: c_int, claimed: *mut u64,
                                                rounds: *mut u64, challenges: *mut u64) -> c_int;
         pub fn zk_sharded_sumcheck_gkr_prove(c: *mut c_void, shards: *const *const zk_table, nprod: usize, nfac: usize, claimed: *const u64,
@@ -221,6 +228,9 @@ pub mod kzg {
             check(unsafe { ffi::zk_kzg_setup_g2(as_limbs(taus), taus.len(), g2.as_mut_ptr()) });
             Self { g1, g2_powers: g2, nvars: taus.len() }
         }
+        /// Optional, once per setup: window-shifted copies of the G1 powers (ceil(256 / 22) x 128 bytes per point of HBM), after which every
+        /// commit_to_polynomial against this setup uses 22-bit windows on one bucket set.  The commitments are the same group elements.
+        pub fn precompute_for_commits(&mut self) { check(unsafe { ffi::zk_g1_bases_precompute(self.g1, 0) }); }
     }
     #[derive(Clone)] pub struct MultilinearKZGProof { pub evaluation: Fr, pub proofs: Vec<G1Projective> }   // multilinear_kzg.rs:17-20
 

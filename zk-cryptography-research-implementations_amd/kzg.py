@@ -130,6 +130,10 @@ class TrustedSetup:
         L.check(_decl().zk_kzg_setup_g1(L.p64(t), t.shape[0], C.byref(h)))
         return cls(G1Bases(_handle=h), t.shape[0], t.copy())
 
+    def precompute_for_commits(self, window_bits=0):
+        """optional, once per setup: window-shifted copies of the G1 powers (zk_g1_bases_precompute); later commits use one bucket set"""
+        return self.g1_powers_of_tau.precompute(window_bits)
+
     @property
     def g2_powers_of_tau(self):
         if self._g2 is None:
