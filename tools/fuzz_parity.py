@@ -60,7 +60,7 @@ def op_evaluate(zk, rng, field, mode):
 
 
 def op_basic(zk, rng, field, mode, big=False):
-    logn = int(rng.integers(17, 20)) if big else int(rng.integers(0, 16))
+    logn = int(rng.integers(17, 23)) if big else int(rng.integers(0, 17))
     t = table(zk, rng, field, 1 << logn, mode)
     prover = zk.Prover.init(field, t)
     proof = prover.prove()
@@ -98,10 +98,14 @@ def op_msm(zk, rng, field, mode):
     a = zk.from_ints(0, [int(rng.integers(1, 1 << 62))])[0]
     d = zk.from_ints(0, [int(rng.integers(0, 3)) if mode != "random" else int(rng.integers(1, 1 << 62))])[0]   # d = 0: all bases equal
     bases = zk.G1Bases.synthetic(n, a, d)
-    c = int(rng.choice([0, 2, 4, 7, 11, 13, 16]))
+    c = int(rng.choice([0, 2, 4, 7, 11, 13, 16, 17, 19, 20, 22]))            # 17 and up: the wide-window sort (round 3)
     got, _ = zk.kzg.msm(zk.MultilinearPolynomial.vector(0, sc), bases, c, True)
     want = O.kzg_commit(sc, bases.points())
     assert np.array_equal(np.asarray(got), np.asarray(want)), ("msm", n, c, mode)
+    if int(rng.integers(0, 4)) == 0:                                          # round 3: precomputed window-shifted bases, one bucket set
+        used = bases.precompute(int(rng.choice([0, 9, 13, 16, 20])))
+        got, st = zk.kzg.msm(zk.MultilinearPolynomial.vector(0, sc), bases, 0, True)
+        assert st["window_bits"] == used and np.array_equal(np.asarray(got), np.asarray(want)), ("msm precomputed", n, used, mode)
 
 
 def op_kzg(zk, rng, field, mode):
