@@ -233,6 +233,7 @@ template <class F> ZK_HD Ufe<F> umul2_std(const Ufe<F> &a1, const Fe<F> &b1, con
     }
     return u_normalize_columns<F>(T);
 }
+template <class F> ZK_HD Ufe<F> u_reduce_once(const Ufe<F> &a);      // below
 // a1 * b1 + a2 * b2 in the stored form, canonical: bit-identical to fe_add(fe_mul(a1, b1), fe_mul(a2, b2))
 template <class F> ZK_HD Fe<F> fe_mul2_u(const Fe<F> &a1, const Fe<F> &b1, const Fe<F> &a2, const Fe<F> &b2) {
     return u_to_limbs32<F>(u_reduce_once<F>(umul2_std<F>(u_from_limbs32<F>(a1), b1, u_from_limbs32<F>(a2), b2)));
