@@ -389,6 +389,23 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
     zk_rounds *r = nullptr;
     ZK_TRY(zk_rounds_new(field, mode, nprod, nfac, nrounds, t, &r));
     clk.mark("rounds handle + init");
+    // The ranks agree on the outcome: a rank whose host side stalled (its kernels gave up and ended; it kept its place in every
+    // collective, so nobody hangs) knows that its proof failed -- the others hold sums it contributed garbage to and cannot tell.  One
+    // more word is summed over the ranks at the very end; any failure fails the proof everywhere.
+    auto collect_agreed = [&]() -> int {
+        const int rc = zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+        if (G == 1) return rc;
+        const std::string mine = rc != ZK_OK ? std::string(zk_last_error()) : std::string();
+        DevBuf flag;
+        ZK_TRY(flag.alloc(8));
+        uint64_t f = rc != ZK_OK ? 1 : 0;
+        ZK_HIP(memcpy_on_stream(flag.p, &f, 8, hipMemcpyHostToDevice));
+        ZK_TRY(c->all_reduce_i64(flag.p, 1));
+        ZK_HIP(memcpy_on_stream(&f, flag.p, 8, hipMemcpyDeviceToHost));
+        if (rc != ZK_OK) { set_last_error(mine); return rc; }
+        if (f != 0) { set_last_error("sharded proof: another rank's proof failed (its host-assisted transcript step stalled or a kernel gave up): this rank's proof is not valid"); return ZK_E_COMM; }
+        return ZK_OK;
+    };
     struct Guard { zk_rounds *r; ~Guard() { zk_rounds_free(r); } } guard{r};
     DevBuf limbs;
     ZK_TRY(limbs.alloc(zk_rounds_limbs_len(r) * 8));
@@ -448,7 +465,7 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
         ZK_HIP(hipGetLastError());
         const zk_table view{field, L * G, rep.p, 0};
         ZK_TRY(zk_rounds_multi_tail(r, &view));
-        return zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+        return collect_agreed();
     }
     if (L * G > kTail) {
         ZK_TRY(ping.alloc(field, L / 2, ntab));
@@ -474,7 +491,7 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
             ZK_TRY(zk_rounds_absorb(r, lp));
         }
         ZK_TRY(zk_rounds_tail(r, cur.data()));
-        return zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+        return collect_agreed();
     }
     // <= kTailLen entries left in the global table: gather them on every rank (global index = j G + rank) and finish replicated
     DevBuf snd, rcv;
@@ -498,7 +515,7 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
         ZK_TRY(zk_rounds_absorb(r, lp));
     }
     ZK_TRY(zk_rounds_tail(r, vp.data()));
-    return zk_rounds_collect(r, t, claimed, messages, challenges, final_values);
+    return collect_agreed();
 }
 
 }  // namespace
