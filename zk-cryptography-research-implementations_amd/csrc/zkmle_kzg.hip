@@ -176,7 +176,7 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     // per lane.  Measured r1 after the bucket update became the unsaturated dual-product form (2^24 terms, bucket phase, ms;
     // lanes 0.8M / 1.3M / 2.4M / 4.4M / 8.6M / 17M): 58.7 / 49.4 / 43.6 / 41.4 / 43.4 / 44.7; minimum 4 / 8 / 16 / 32 points per lane
     // at 2^20 terms: 4.13 / 3.59 / 3.50 / 3.81.  ZK_MSM_SEG_SHIFT / ZK_MSM_SEG_MIN override, for measurements.
-    static const int seg_shift = [] { const char *e = getenv("ZK_MSM_SEG_SHIFT"); int k = e ? atoi(e) : 22; return k < 10 ? 10 : (k > 24 ? 24 : k); }();
+    static const int seg_shift = [] { const char *e = getenv("ZK_MSM_SEG_SHIFT"); int k = e ? atoi(e) : 20; return k < 10 ? 10 : (k > 24 ? 24 : k); }();   // r3, balanced runs (2^24, c = 16 / precomputed c = 22, ms; shift 19 / 20 / 21 / 22 / 23): 43.35 / 42.49 / 42.61 / 43.19 / 44.28 and 36.11 / 35.61 / 36.32 / 36.93 / 37.32
     size_t seg_target = ((size_t)n * nwin1) >> seg_shift;
     static const unsigned seg_min = [] { const char *e = getenv("ZK_MSM_SEG_MIN"); int k = e ? atoi(e) : 32; return (unsigned)(k < 2 ? 2 : k); }();   // r3, balanced runs, 2^20 terms (bucket phase, ms; 16 / 32 / 64): 2.97 / 2.86 / 2.86
     unsigned seg_len = (unsigned)(seg_target < seg_min ? seg_min : seg_target);
