@@ -526,6 +526,8 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
     }
     std::vector<uint64_t> hs(base[nlayers] * L64);
     ZK_TRY(ps->collect(tr.t, hs.data()));                                            // the proof's only download
+    // (a clean proof's collect does not wait for the stream to drain -- the host already holds every byte: the layer timings do)
+    if (ms_layers && nlayers) ZK_HIP(hipEventSynchronize(ev[2 * nlayers - 1]));
     auto slot = [&](size_t s) { return hs.data() + s * L64; };
     size_t coff = 0, choff = 0;
     for (size_t l = 0; l < nlayers; l++) {
