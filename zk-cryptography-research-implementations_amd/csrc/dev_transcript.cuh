@@ -292,13 +292,23 @@ template <class F> __device__ __forceinline__ void round_finish_in_producer(cons
     }
     if (!__builtin_amdgcn_readfirstlane(last)) return;
     Fe<F> e = fe_zero<F>();
+    unsigned long long v[F::N + 1];
+#pragma unroll
+    for (int k = 0; k <= F::N; k++) v[k] = 0;
     if (mine) {
-        unsigned long long v[F::N + 1];
 #pragma unroll
         for (int k = 0; k < F::N; k++) v[k] = __hip_atomic_load(acc + (size_t)k * kMultiAccStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v[F::N] = 0;
 #pragma unroll
         for (int k = 0; k < F::N; k++) __hip_atomic_store(acc + (size_t)k * kMultiAccStride, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (f.limbs_out) {                                       // sums of 32-bit limbs, carries unpropagated: what the all-reduce adds up
+        if ((int)lane < f.npts) {
+#pragma unroll
+            for (int k = 0; k <= F::N; k++) f.limbs_out[(size_t)lane * (F::N + 1) + k] = v[k];
+        }
+        return;
+    }
+    if (mine) {
         Wide<F> w;
         unsigned long long c = 0;
 #pragma unroll

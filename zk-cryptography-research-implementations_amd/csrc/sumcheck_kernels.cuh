@@ -38,6 +38,7 @@ struct RoundFin {
     int npts;                // evaluations per round
     int skip1;               // the point 1 is not evaluated: its words are neither written nor read (the host derives it)
     unsigned group;          // workgroups per arrival group
+    uint64_t *limbs_out;     // sharded tables: the npts sums leave as (N + 1) 32-bit limbs in 64-bit words for the all-reduce; nothing is posted
     HostMailbox *mb;
     uint64_t seq;
     void *proof;

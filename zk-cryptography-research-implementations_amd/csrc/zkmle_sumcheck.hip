@@ -423,9 +423,15 @@ template <class F> struct DeviceRounds {
         push_req(Req{kRound, mode, npts, with_claim, derive_prev, 0, claim_slot, msg_slot, chal_slot, 0, {0, 0, 0, 0, 0, 0, 0}});
         unsigned group = 32;
         while ((unsigned)(grid + group - 1) / group > 200u) group *= 2;   // one 64-byte counter slot per group (context.h kSyncCounterBytes)
-        *out = RoundFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), npts, derive_prev, group, mb_dev, (uint64_t)nreq(), proof(),
+        *out = RoundFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), npts, derive_prev, group, nullptr, mb_dev, (uint64_t)nreq(), proof(),
                         chal_slot};
         return ZK_OK;
+    }
+    // the same for a sharded table: the kernel's last workgroup leaves the npts sums as limb words for the all-reduce, nothing is posted
+    RoundFin round_fin_limbs(int grid, int npts, int skip1, uint64_t *limbs_out) const {
+        unsigned group = 32;
+        while ((unsigned)(grid + group - 1) / group > 200u) group *= 2;
+        return RoundFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), npts, skip1, group, limbs_out, nullptr, 0, nullptr, 0};
     }
     // host mode, basic sumcheck (basic_multi.cuh): rounds round .. round + m - 1 from the 2^m segment sums an all-reduce has left as limb
     // words (sharded table); slots of round k: 1 + 3 k, 2 + 3 k (sums), 3 + 3 k (challenge), claim 0
@@ -1056,9 +1062,10 @@ template <class F> struct RoundsImpl : RoundsBase {
         int grid = reduce_grid_for(half);
         void *part;
         ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
-        ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid)));
+        const RoundFin fin = dr.round_fin_limbs(grid, (int)npts, 0, limbs);          // the kernel's last workgroup writes the limbs
+        ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid, 0, &fin)));
         skipped1 = false;
-        return to_limbs(part, grid, limbs);
+        return ZK_OK;
     }
     int fold_evals(const zk_table *const *in, zk_table *const *out, uint64_t *limbs) override {
         ZK_TRY(check_tables(in, 2));
@@ -1076,9 +1083,10 @@ template <class F> struct RoundsImpl : RoundsBase {
             void *part;
             ZK_TRY(scratch(4 * F::N * ((size_t)kMaxReduceBlocks * (kMaxFactors + 1) + kMaxFactors + 1), &part));
             const int skip1 = q >= ((size_t)1 << 14) ? 1 : 0;
-            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true)));
+            const int g = fold_round_takes_split((int)nprod, (int)nfac, q, true) ? (int)(q / 64) : grid;
+            const RoundFin fin = dr.round_fin_limbs(g, (int)npts, skip1, limbs);
+            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true, &fin)));
             skipped1 = skip1 != 0;                                       // e(1) = claim - e(0), after the all-reduce
-            ZK_TRY(to_limbs(part, grid, limbs));
         } else {                                                         // 2 entries -> 1: nothing left to evaluate
             for (size_t k = 0; k < ntab; k++) {
                 fold_kernel<F><<<1, 64, 0, cur_stream()>>>(tabs.in[k], tabs.out[k], 1, 0, fe_zero<F>(), rp);
