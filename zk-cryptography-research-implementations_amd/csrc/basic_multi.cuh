@@ -14,8 +14,8 @@
 namespace zk {
 
 // kMultiMax (mle_kernels.cuh) = 8 rounds per exchange of a grid-wide pass: 2^8 segment sums go to the mailbox's `big` area, 8 challenges
-// come back, one answer line each.  The one-workgroup tail keeps four rounds per exchange (its sums and challenges live in LDS).
-constexpr int kTailMultiMax = 4;
+// come back, one answer line each.  The one-workgroup tail runs up to six rounds per exchange (its sums and challenges live in LDS).
+constexpr int kTailMultiMax = 6;
 
 // ---- the exchange inside the producer ----------------------------------------------------------------------------------------
 // r2 ran a one-workgroup kernel (multi_finish_kernel) behind every pass: reduce the partials, post, wait for the challenges.  r3: the
