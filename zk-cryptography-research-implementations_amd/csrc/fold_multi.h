@@ -47,4 +47,22 @@ int launch_foldk(const void *in, void *out, size_t n, int k, const void *const *
     return ZK_OK;
 }
 
+// a pass with a short output and no segment sums: kFoldSplit lanes per output (foldk_split_kernel)
+template <class F> int launch_foldk_split(const void *in, void *out, size_t n, int k, const void *const *rp) {
+    FoldKArgs a{};
+    a.in = in; a.out = out; a.n = n;
+    for (int i = 0; i < k; i++) a.r[i] = rp[i];
+    const unsigned grid = (unsigned)((n + kFoldSplitBlock / kFoldSplit - 1) / (kFoldSplitBlock / kFoldSplit));
+    switch (k) {
+        case 4: foldk_split_kernel<F, 4><<<grid, kFoldSplitBlock, 0, cur_stream()>>>(a); break;
+        case 5: foldk_split_kernel<F, 5><<<grid, kFoldSplitBlock, 0, cur_stream()>>>(a); break;
+        case 6: foldk_split_kernel<F, 6><<<grid, kFoldSplitBlock, 0, cur_stream()>>>(a); break;
+        case 7: foldk_split_kernel<F, 7><<<grid, kFoldSplitBlock, 0, cur_stream()>>>(a); break;
+        case 8: foldk_split_kernel<F, 8><<<grid, kFoldSplitBlock, 0, cur_stream()>>>(a); break;
+        default: return ZK_E_ARG;
+    }
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
 }  // namespace zk

@@ -377,6 +377,8 @@ template <class F, int K, bool FIN = false> __global__ void __launch_bounds__(kB
             RawAcc<F> ra;
 #pragma unroll
             for (int c = 0; c < 2 * UParams<F>::L; c++) ra.c[c] = 0;
+            // (r3: fetching the next batch while this one is multiplied changed nothing -- 2^24 inputs x 81 multiply-adds each is what the
+            // pass costs, ~105 us whatever K -- and took the kernel from 117 to 160 VGPRs)
 #pragma unroll 1
             for (int i0 = 0; i0 < (1 << K); i0 += kRawCarryEvery) {
                 Fe<F> x[kRawCarryEvery];
@@ -401,6 +403,54 @@ template <class F, int K, bool FIN = false> __global__ void __launch_bounds__(kB
         }
     }
     if (have) fe_store<F>(a.partials, blockIdx.x, tot);
+}
+
+// A pass with a SHORT output (n <= 2^13 entries: the last one before a one-workgroup tail) has too few outputs to fill the chip with one
+// lane per output -- 2^11 outputs from 2^17 inputs are 8 workgroups whose lanes read 64 inputs one chunk after the other, 34 us for 4 MB
+// (r3 trace).  Here kFoldSplit lanes share an output: lane part q sums inputs i = q * 2^K / kFoldSplit ... with the same weights and
+// the same unreduced accumulation as foldk_seg_sums_kernel, reduces once, and the parts meet in LDS.  Field addition is exact, so the
+// value is the one the sequential fold (mle.rs:118-127, K times) leaves.  No segment sums: the tail computes its own.
+constexpr int kFoldSplit = 8;
+constexpr int kFoldSplitBlock = 64;          // one wave per workgroup: 2^11 outputs are 256 workgroups, one per CU
+template <class F, int K> __global__ void __launch_bounds__(kFoldSplitBlock) foldk_split_kernel(FoldKArgs a) {
+    static_assert(K >= 4 && K <= 8, "2^K inputs per output, at least two per lane");
+    constexpr int kOut = kFoldSplitBlock / kFoldSplit, kPer = (1 << K) / kFoldSplit, kStep = kPer < kRawCarryEvery ? kPer : kRawCarryEvery;
+    __shared__ Ufe<F> sw[1 << K];
+    __shared__ Fe<F> parts[kFoldSplit][kOut];
+    for (unsigned e = threadIdx.x; e < (1u << K); e += kFoldSplitBlock) {
+        Fe<F> w = fe_one<F>();
+#pragma unroll
+        for (int l = 0; l < K; l++) {
+            const Fe<F> r = fe_load<F>(a.r[l], 0);
+            w = fe_mul<F>(w, ((e >> (K - 1 - l)) & 1u) ? r : fe_sub<F>(fe_one<F>(), r));
+        }
+        sw[e] = u_reduce_once<F>(u_from_std<F>(w));
+    }
+    __syncthreads();
+    const unsigned q = threadIdx.x / kOut, jj = threadIdx.x % kOut;
+    const size_t j = (size_t)blockIdx.x * kOut + jj;
+    if (j < a.n) {
+        RawAcc<F> ra;
+#pragma unroll
+        for (int c = 0; c < 2 * UParams<F>::L; c++) ra.c[c] = 0;
+#pragma unroll
+        for (int i0 = 0; i0 < kPer; i0 += kStep) {
+            Fe<F> x[kStep];
+#pragma unroll
+            for (int i = 0; i < kStep; i++) x[i] = fe_load<F>(a.in, j + (size_t)(q * kPer + i0 + i) * a.n);
+#pragma unroll
+            for (int i = 0; i < kStep; i++) raw_mul_add<F>(ra, u_from_limbs32<F>(x[i]), sw[q * kPer + i0 + i]);
+            raw_normalize<F>(ra);
+        }
+        parts[q][jj] = u_to_limbs32<F>(u_reduce_once<F>(raw_mont_reduce<F>(ra)));
+    }
+    __syncthreads();
+    if (q == 0 && j < a.n) {
+        Fe<F> v = parts[0][jj];
+#pragma unroll
+        for (int p = 1; p < kFoldSplit; p++) v = fe_add<F>(v, parts[p][jj]);
+        fe_store<F>(a.out, j, v);
+    }
 }
 
 // ---- element-wise and tensor operations --------------------------------------------------------------

@@ -605,16 +605,11 @@ template <class F> int launch_seg_sums(const void *in, size_t len, int m, void *
     return ZK_OK;
 }
 // One pass that folds k variables (challenges at rp[0 .. k)) of `in` (n << k entries) into `out` (n entries).  A pass that leaves no
-// segment sums and a SHORT output (the last one before the tail: 2^11 entries from 2^17) would run on n / 256 workgroups, each lane reading
-// 2^k inputs one chunk after the other -- 34 us for 4 MB (r3 trace); it goes as two passes of about k / 2 variables through `tmp`
-// (>= n << (k - k / 2) entries), 64 and 8 workgroups with 8 loads per lane each.
+// segment sums and a SHORT output (the last one before the tail: 2^11 entries from 2^17) takes the split form, eight lanes per output
+// (mle_kernels.cuh foldk_split_kernel: one lane per output was 34 us for 4 MB, two passes of k / 2 variables 19 us).
 template <class F>
-int fold_pass(const void *in, void *out, void *tmp, size_t n, int k, const void *const *rp, int m_next, void *part, unsigned *bps, const MultiFin *fin) {
-    if (m_next == 0 && k >= 4 && n <= ((size_t)1 << 13) && tmp) {
-        const int k1 = k / 2;
-        ZK_TRY((launch_foldk<F, true>(in, tmp, n << (k - k1), k1, rp, 0, part, bps, nullptr)));
-        return launch_foldk<F, true>(tmp, out, n, k - k1, rp + k1, 0, part, bps, nullptr);
-    }
+int fold_pass(const void *in, void *out, size_t n, int k, const void *const *rp, int m_next, void *part, unsigned *bps, const MultiFin *fin) {
+    if (m_next == 0 && k >= 4 && n <= ((size_t)1 << 13)) return launch_foldk_split<F>(in, out, n, k, rp);
     return launch_foldk<F, true>(in, out, n, k, rp, m_next, part, bps, fin);
 }
 
@@ -629,7 +624,7 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
     double t1 = now_ms();
     g_stats = zk_sumcheck_stats{nvars, (float)(t1 - t0), 0.f};
     // working buffers: len/2 and len/4 elements, plus reduction partials
-    DevBuf bufA, bufB, bufT;
+    DevBuf bufA, bufB;
     ZK_TRY(bufA.alloc((len / 2) * esz));
     ZK_TRY(bufB.alloc((len / 4) * esz));
     void *part;
@@ -663,12 +658,7 @@ template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum,
                 for (int i = 0; i < m; i++) rp[i] = dr.slot_ptr(3 + 3 * (round + (size_t)i));
                 if (mn) ZK_TRY(dr.multi_fin(mn, round + (size_t)m, &fin));
                 // :61-63 m times, fused with :74-89 and the exchange of the next rounds
-                void *tmp = nullptr;
-                if (mn == 0 && m >= 4 && n <= ((size_t)1 << 13)) {              // fold_pass splits a short last pass in two
-                    ZK_TRY(bufT.alloc((n << (m - m / 2)) * esz));
-                    tmp = bufT.p;
-                }
-                ZK_TRY((fold_pass<F>(cur, dst, tmp, n, m, rp, mn, part, &bps, mn ? &fin : nullptr)));
+                ZK_TRY((fold_pass<F>(cur, dst, n, m, rp, mn, part, &bps, mn ? &fin : nullptr)));
                 cur = dst;
                 void *nx = other;
                 other = dst;
@@ -1031,7 +1021,7 @@ template <class F> struct RoundsImpl : RoundsBase {
     bool tail_done = false;
     bool skipped1 = false;                               // the limbs on their way lack the point 1 (derived in absorb)
     DeviceRounds<F> dr;
-    DevBuf tailbuf, foldtmp;
+    DevBuf tailbuf;
 
     int init(int mode_, size_t nprod_, size_t nfac_, size_t nrounds_, Transcript &tr) {
         mode = mode_; nprod = nprod_; nfac = nfac_; ntab = nprod * nfac; npts = nfac + 1; nrounds = nrounds_;
@@ -1167,12 +1157,7 @@ template <class F> struct RoundsImpl : RoundsBase {
         unsigned bps;
         MultiFin fin = dr.multi_fin_limbs((int)m_next, limbs);
         if (m_next && !limbs) ZK_TRY(dr.multi_fin((int)m_next, round, &fin));
-        void *tmp = nullptr;
-        if (m_next == 0 && k >= 4 && n <= ((size_t)1 << 13)) {                    // fold_pass splits a short last pass in two
-            ZK_TRY(foldtmp.alloc((n << (k - k / 2)) * 4 * F::N));
-            tmp = foldtmp.p;
-        }
-        ZK_TRY((fold_pass<F>(in->dptr, out->dptr, tmp, n, (int)k, rp, (int)m_next, part, &bps, m_next ? &fin : nullptr)));
+        ZK_TRY((fold_pass<F>(in->dptr, out->dptr, n, (int)k, rp, (int)m_next, part, &bps, m_next ? &fin : nullptr)));
         out->len = n;
         if (m_next && !limbs) round += m_next;
         return ZK_OK;
