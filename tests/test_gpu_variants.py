@@ -18,8 +18,8 @@ DIGESTS = {}
 
 @pytest.mark.parametrize("env", [{}, {"ZK_HOST_TRANSCRIPT": "0"}, {"ZK_BASIC_ROUNDS_PER_PASS": "1"}, {"ZK_BASIC_ROUNDS_PER_PASS": "2"},
                                  {"ZK_BASIC_ROUNDS_PER_PASS": "3"}, {"ZK_BASIC_ROUNDS_PER_PASS": "4"}, {"ZK_BASIC_ROUNDS_PER_PASS": "6"},
-                                 {"ZK_GKR_WEIGHT_TABLE": "1"}],
-                         ids=["default", "device_step", "k1", "k2", "k3", "k4", "k6", "weight_table"])
+                                 {"ZK_BASIC_ROUNDS_PER_PASS": "8"}, {"ZK_GKR_WEIGHT_TABLE": "1"}],
+                         ids=["default", "device_step", "k1", "k2", "k3", "k4", "k6", "k8", "weight_table"])
 def test_variant_reproduces_oracle_proofs(env):
     e = dict(os.environ)
     e.update(env)
