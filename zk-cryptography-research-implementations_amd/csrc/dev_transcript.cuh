@@ -502,36 +502,11 @@ __global__ void __launch_bounds__(kFinishBlock) sumcheck_finish_kernel(FinishArg
 // (`limbs[t * (N + 1) + k]`): the sum over <= 2^32 ranks of such vectors is a plain element-wise integer sum, i.e. ONE
 // all-reduce(SUM, int64) over RCCL, with no carries to move between words.  Every rank then runs the same transcript step on
 // the summed limbs (carry, reduce mod p, message, absorb, challenge): replicated sponge, no broadcast, no host round trip.
-template <class F>
-__global__ void __launch_bounds__(kFinishBlock) partials_to_limbs_kernel(const void *__restrict__ partials, size_t count, int npts,
-                                                                          uint64_t *__restrict__ limbs) {
-    __shared__ Wide<F> sh[kMaxPts * 16];
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    Wide<F> acc[kMaxPts];
-#pragma unroll
-    for (int t = 0; t < kMaxPts; t++) {
-        acc[t] = wide_zero<F>();
-        if (t < npts)
-            for (size_t i = tid; i < count; i += blockDim.x) wide_add_fe<F>(acc[t], fe_load<F>(partials, (size_t)t * count + i));
-    }
-    wave_reduce_wide<F, kMaxPts>(acc, npts);
-    if (lane == 63) {
-#pragma unroll
-        for (int t = 0; t < kMaxPts; t++) sh[t * 16 + wave] = acc[t];
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    const unsigned t = lane >> 4, w = lane & 15u;
-    Wide<F> v = w < nwaves ? sh[lane] : wide_zero<F>();
-    row_reduce_wide<F>(v);
-    if (w == 15 && (int)t < npts) {
-#pragma unroll
-        for (int k = 0; k <= F::N; k++) limbs[t * (F::N + 1) + k] = v.l[k];
-    }
-}
+// (r3: the words are written by the round kernel's last workgroup, round_finish_in_producer with `limbs_out`; r1-r2 ran a one-workgroup
+// partials_to_limbs_kernel behind every round kernel for this.)
 
 struct LimbsFinishArgs {
-    const uint64_t *limbs;   // element-wise sums over the ranks of partials_to_limbs_kernel's output
+    const uint64_t *limbs;   // element-wise sums over the ranks of the round kernels' limbs_out
     RoundCtx ctx;
     int with_claim;
     int flags;               // kDerive1: launched with 128 lanes, the second wave evaluates the previous round's message

@@ -1036,13 +1036,6 @@ template <class F> struct RoundsImpl : RoundsBase {
         if (t[0]->field != F::ID || t[0]->len < minlen) return ZK_E_ARG;
         return ZK_OK;
     }
-    int to_limbs(void *part, int grid, uint64_t *limbs) {
-        size_t threads = ((size_t)grid + 63) / 64 * 64;
-        if (threads > (size_t)kFinishBlock) threads = kFinishBlock;
-        partials_to_limbs_kernel<F><<<1, (int)threads, 0, cur_stream()>>>(part, (size_t)grid, (int)npts, limbs);
-        ZK_HIP(hipGetLastError());
-        return ZK_OK;
-    }
     int evals(const zk_table *const *tables, uint64_t *limbs) override {
         ZK_TRY(check_tables(tables, 2));
         if (!limbs || round >= nrounds) return ZK_E_ARG;
