@@ -363,6 +363,9 @@ def run_rank(env, args, zk):
         # what was timed is a correct fold: sampled outputs of the last launch against the oracle on the host mirror of the inputs
         result["post_check"] = post_check_fold(zk, field, out, r, seed, first, stride, half)
     del table, out
+    watchdog = None
+    if world > 1 and (env.tgroup is None or (rank == 0 and "ZK_BENCH_LEG_DEADLINE" in os.environ)):   # rehearsals: only when asked for (tests)
+        watchdog = secondary_legs_watchdog(env, args, result)
     if world > 1 and strong and not args.no_weak:            # secondary: the weak-scaling form (a 2^log-n table per GPU)
         wt, wtab, wout = fold_leg(env, zk, n_global, SEED_TABLE + rank, 0, 1, r, min(args.steps, 300), min(args.warmup, 20), prewarm_s=0.0)
         wb = 96.0 * (n_global // 2) / (wt["kernel_ms"] * 1e-3) / 1e9
@@ -401,7 +404,34 @@ def run_rank(env, args, zk):
         result["cpu_baseline"] = cpu_baseline(zk, field)
     if failed:
         result["failed_legs"] = failed
+    if watchdog:
+        watchdog.cancel()
     return result
+
+
+def secondary_legs_watchdog(env, args, result):
+    """N > 1, one process per GPU: the headline (the sharded fold, no data-path collective) is measured; the legs that follow run the
+    provers' collectives.  An exception in one of them is caught and reported (`failed_legs`); a HANG inside a collective would take the
+    headline with it.  After ZK_BENCH_LEG_DEADLINE seconds (default 600) rank 0 prints the line with what has finished and every rank
+    leaves (exit code 0, or 3 under --require-rccl)."""
+    headline = json.dumps(dict(result, failed_legs=["watchdog: the legs after the headline did not finish in time (none reported)"]))
+    deadline = float(os.environ.get("ZK_BENCH_LEG_DEADLINE", "600"))
+
+    def fire():
+        if env.rank == 0:
+            try:
+                done = dict(result)
+                done["failed_legs"] = list(done.get("failed_legs", [])) + [f"watchdog: a leg after {sorted(k for k in done if k in ('weak', 'sharded_sumcheck', 'config5_strong', 'msm')) or 'the headline'} did not finish within {deadline:.0f} s"]
+                line = json.dumps(done)
+            except Exception:                               # noqa: BLE001  (the main thread was adding a key)
+                line = headline
+            print(line, flush=True)
+        os._exit(3 if args.require_rccl else 0)
+
+    t = threading.Timer(deadline, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 # ---- checks of what was timed ---------------------------------------------------------------------------------------------

@@ -72,3 +72,18 @@ def test_eight_rank_rehearsal_is_strong_scaling_of_one_table():
     assert c5["sumcheck"]["verifier_equations_hold"] is True and c5["sumcheck"]["rounds"] == 16
     assert c5["msm"]["same_point_on_every_rank"] is True and c5["msm"]["post_check"]["holds"] is True
     assert "ms_per_proof" in d["sharded_sumcheck"] and d["weak"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_a_stuck_secondary_leg_does_not_take_the_headline_with_it():
+    # N > 1: the legs after the headline run collectives; past ZK_BENCH_LEG_DEADLINE the line is printed with what has finished (bench.py
+    # secondary_legs_watchdog).  Here the deadline is shorter than the legs take, on the 8-rank rehearsal.
+    p = run(["--gpus", "8", "--rehearse", "--steps", "4", "--warmup", "1", "--log-n", "18", "--msm-reps", "1", "--no-cpu-baseline"],
+            env={"ZK_BENCH_LEG_DEADLINE": "0.05"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = last_json(p.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0 and "roofline" in d
+    assert any("watchdog" in leg for leg in d["failed_legs"])
+    p = run(["--gpus", "8", "--rehearse", "--steps", "4", "--warmup", "1", "--log-n", "18", "--msm-reps", "1", "--no-cpu-baseline", "--require-rccl"],
+            env={"ZK_BENCH_LEG_DEADLINE": "0.05"})
+    assert p.returncode != 0
