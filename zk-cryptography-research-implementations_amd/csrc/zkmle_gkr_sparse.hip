@@ -78,13 +78,63 @@ struct GateWeights {
     const void *w;                       // non-null: the table of weights in gate order
     const void *ah, *al, *bh, *bl;       // else: half tables of alpha eq(rb, .) and (bh non-null) beta eq(rc, .)
     unsigned lbits;
+    const void *uah, *ual, *ubh, *ubl;   // the same half tables in the products' internal form (UHalves below); uah non-null: the kernels use these
 };
 // the table gathered at a gate's other index: an array (W in phase 1), or the half tables of an eq table (eq(rb*, .) in phase 2)
 struct OtherTable {
     const void *tab;                     // non-null: the table itself
     const void *hi, *lo;                 // else its half tables
     unsigned lbits;
+    const void *uhi, *ulo;               // the half tables in the internal form (with GateWeights::uah)
 };
+// ---- half tables in the products' internal form (r3) ------------------------------------------------------------------------------
+// The table kernels are VALU-bound, and more than half of their VALU work was not multiply-adds but what surrounds a product on stored
+// operands: 32-bit -> 29-bit limbs of one operand, digit extraction of the other, conditional subtraction and 29-bit -> 32-bit limbs of
+// the result -- ~190 instructions around 162 multiply-adds, four products per gate.  The half tables are 2^11 entries each and are
+// built once per layer, so they are converted once: L limbs of 29 bits per entry (ufield.cuh), and the Montgomery factors are chosen so that
+// a gate's chain of products needs no conversion until its result is stored.  With R = 2^(32 N) (the stored form) and U = 2^(29 L):
+//   weights:  ah' = limbs29(ah R), al' = al U  ->  umul2(ah', al', bh', bl') = (ah al + bh bl) R = the weight in the stored form, below 1.06 p;
+//   other:    hi' = hi U, lo' = lo U            ->  umul(hi', lo') = hi lo U;   umul(w R, h U) = w h R, the stored form of the product;
+//   or a stored table entry x R                 ->  umul_std(w R, x R) = w x R  (digits of x: the one conversion left).
+// U / p = 2^6.1, so every one of these is below 1.5 p and one conditional subtraction gives the canonical limbs the old chain gave.
+template <class F> constexpr int u_stride_words() { return (UParams<F>::L + 3) / 4 * 4; }          // 16-byte aligned entries
+template <class F> __device__ __forceinline__ Ufe<F> ufe_load(const void *tab, uint32_t idx) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(tab) + (size_t)idx * u_stride_words<F>();
+    Ufe<F> r;
+#pragma unroll
+    for (int j = 0; j < UParams<F>::L; j++) r.l[j] = p[j];
+    return r;
+}
+// out[i] = in[i] as 29-bit limbs: the stored integer itself (mont = 0) or times U / R (mont = 1), fully reduced; two tables per launch
+template <class F> __global__ void halves_to_u_kernel(const void *__restrict__ in0, uint32_t n0, int mont0, void *__restrict__ out0,
+                                                      const void *__restrict__ in1, uint32_t n1, int mont1, void *__restrict__ out1) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool second = i >= n0;
+    if (second) i -= n0;
+    if (second && i >= n1) return;
+    const Fe<F> x = fe_load<F>(second ? in1 : in0, i);
+    const Ufe<F> u = (second ? mont1 : mont0) ? u_reduce_once<F>(u_from_std<F>(x)) : u_from_limbs32<F>(x);
+    uint32_t *o = reinterpret_cast<uint32_t *>(second ? out1 : out0) + (size_t)i * u_stride_words<F>();
+#pragma unroll
+    for (int j = 0; j < u_stride_words<F>(); j++) o[j] = j < UParams<F>::L ? u.l[j] : 0u;
+}
+template <class F> int halves_to_u(const void *hi, int mont_hi, const void *lo, unsigned nbits, unsigned lbits, DevBuf &uhi, DevBuf &ulo) {
+    const uint32_t nhi = 1u << (nbits - lbits), nlo = 1u << lbits;
+    ZK_TRY(uhi.alloc((size_t)nhi * u_stride_words<F>() * 4));
+    ZK_TRY(ulo.alloc((size_t)nlo * u_stride_words<F>() * 4));
+    halves_to_u_kernel<F><<<(nhi + nlo + kBlock - 1) / kBlock, kBlock, 0, cur_stream()>>>(hi, nhi, mont_hi, uhi.p, lo, nlo, 1, ulo.p);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+template <class F> __device__ __forceinline__ Ufe<F> gate_weight_u(const GateWeights &g, uint32_t idx) {        // the weight, stored form, as 29-bit limbs below 1.06 p
+    const uint32_t h = idx >> g.lbits, l = idx & ((1u << g.lbits) - 1u);
+    if (g.ubh) return umul2<F>(ufe_load<F>(g.uah, h), ufe_load<F>(g.ual, l), ufe_load<F>(g.ubh, h), ufe_load<F>(g.ubl, l));
+    return umul<F>(ufe_load<F>(g.uah, h), ufe_load<F>(g.ual, l));
+}
+template <class F> __device__ __forceinline__ Ufe<F> other_times_u(const OtherTable &t, uint32_t idx, const Ufe<F> &wu) {   // w x entry, stored form, below 1.5 p
+    if (t.tab) return umul_std<F>(wu, fe_load<F>(t.tab, idx));
+    return umul<F>(wu, umul<F>(ufe_load<F>(t.uhi, idx >> t.lbits), ufe_load<F>(t.ulo, idx & ((1u << t.lbits) - 1u))));
+}
 template <class F> __device__ __forceinline__ Fe<F> other_entry(const OtherTable &t, uint32_t idx) {
     if (t.tab) return fe_load<F>(t.tab, idx);
     return fe_mul<F>(fe_load<F>(t.hi, idx >> t.lbits), fe_load<F>(t.lo, idx & ((1u << t.lbits) - 1u)));
@@ -96,16 +146,18 @@ template <class F> __device__ __forceinline__ Fe<F> gate_weight(const GateWeight
     return fe_mul<F>(fe_load<F>(g.ah, h), fe_load<F>(g.al, l));
 }
 struct Phase1Op {            // per gate: w and t = w W[right]; add gate: H1 += w, H0 += t; mul gate: H1 += t
+    static constexpr bool kNeedsWeight = true;
     template <class F> static __device__ __forceinline__ void terms(const Fe<F> &wg, const Fe<F> &t, uint32_t op, Fe<F> &x, Fe<F> &y) {
         if (op == 0) { x = wg; y = t; } else { x = t; y = fe_zero<F>(); }
     }
 };
 struct Phase2Op {            // per gate: t = w eqL[left]; add gate: A += t; mul gate: M += t
+    static constexpr bool kNeedsWeight = false;
     template <class F> static __device__ __forceinline__ void terms(const Fe<F> &, const Fe<F> &t, uint32_t op, Fe<F> &x, Fe<F> &y) {
         if (op == 0) { x = t; y = fe_zero<F>(); } else { x = fe_zero<F>(); y = t; }
     }
 };
-template <class F, class Op>
+template <class F, class Op, bool UH>
 __device__ __forceinline__ void grouped_pair_sums(const uint32_t *__restrict__ start, size_t nb, const GateWeights &gw, const uint32_t *__restrict__ order,
                                                   const uint32_t *__restrict__ other, const uint32_t *__restrict__ op, const OtherTable &tab,
                                                   Fe<F> &sx, Fe<F> &sy) {
@@ -122,9 +174,16 @@ __device__ __forceinline__ void grouped_pair_sums(const uint32_t *__restrict__ s
         const uint32_t e = base + tid;                                                  // one lane per gate
         if (e < e1) {
             const uint32_t oi = order[e], ti = other[e], pi = op[e];
-            const Fe<F> x = other_entry<F>(tab, ti);
-            const Fe<F> wg = gate_weight<F>(gw, oi);
-            Op::template terms<F>(wg, fe_mul<F>(wg, x), pi, cx[tid], cy[tid]);
+            if constexpr (UH) {                                                         // half tables in the internal form: no conversions inside the chain
+                const Ufe<F> wu = gate_weight_u<F>(gw, oi);
+                const Fe<F> t = u_to_limbs32<F>(u_reduce_once<F>(other_times_u<F>(tab, ti, wu)));
+                const Fe<F> wg = Op::kNeedsWeight ? u_to_limbs32<F>(u_reduce_once<F>(wu)) : fe_zero<F>();
+                Op::template terms<F>(wg, t, pi, cx[tid], cy[tid]);
+            } else {
+                const Fe<F> x = other_entry<F>(tab, ti);
+                const Fe<F> wg = gate_weight<F>(gw, oi);
+                Op::template terms<F>(wg, fe_mul<F>(wg, x), pi, cx[tid], cy[tid]);
+            }
         }
         __syncthreads();
         const uint32_t lo = rs > base ? rs : base, hi = re < base + kBlock ? re : base + (uint32_t)kBlock;
@@ -136,12 +195,12 @@ __device__ __forceinline__ void grouped_pair_sums(const uint32_t *__restrict__ s
     }
 }
 // `widx`: the group's order list (gw.w) or the gates' output indices in grouped order (half tables)
-template <class F> __global__ void __launch_bounds__(kBlock) phase1_tables_kernel(const uint32_t *__restrict__ start, size_t nb, GateWeights gw,
+template <class F, bool UH> __global__ void __launch_bounds__(kBlock) phase1_tables_kernel(const uint32_t *__restrict__ start, size_t nb, GateWeights gw,
                                                         const uint32_t *__restrict__ widx, const uint32_t *__restrict__ right_l,
                                                         const uint32_t *__restrict__ op_l,
                                                         const void *__restrict__ W, void *__restrict__ H1, void *__restrict__ H0) {
     Fe<F> h1, h0;
-    grouped_pair_sums<F, Phase1Op>(start, nb, gw, widx, right_l, op_l, OtherTable{W, nullptr, nullptr, 0}, h1, h0);
+    grouped_pair_sums<F, Phase1Op, UH>(start, nb, gw, widx, right_l, op_l, OtherTable{W, nullptr, nullptr, 0, nullptr, nullptr}, h1, h0);
     const size_t b = (size_t)blockIdx.x * kPhaseGroups + threadIdx.x;
     if (threadIdx.x >= (unsigned)kPhaseGroups || b >= nb) return;
     fe_store<F>(H1, b, h1);
@@ -149,12 +208,12 @@ template <class F> __global__ void __launch_bounds__(kBlock) phase1_tables_kerne
 }
 // gates grouped by right index c: A(c) = sum of the add gates' w eqL[left], M(c) the same over the mul gates;
 // stored: C = A + u M and A, so that phase 2 is the sumcheck of C(c) W(c) + u A(c)  (= A (u + W) + M u W)
-template <class F> __global__ void __launch_bounds__(kBlock) phase2_tables_kernel(const uint32_t *__restrict__ start, size_t nc, GateWeights gw,
+template <class F, bool UH> __global__ void __launch_bounds__(kBlock) phase2_tables_kernel(const uint32_t *__restrict__ start, size_t nc, GateWeights gw,
                                                         const uint32_t *__restrict__ widx, const uint32_t *__restrict__ left_r,
                                                         const uint32_t *__restrict__ op_r,
                                                         OtherTable eqL, const void *__restrict__ u_dev, void *__restrict__ Cc, void *__restrict__ A) {
     Fe<F> a, m;
-    grouped_pair_sums<F, Phase2Op>(start, nc, gw, widx, left_r, op_r, eqL, a, m);
+    grouped_pair_sums<F, Phase2Op, UH>(start, nc, gw, widx, left_r, op_r, eqL, a, m);
     const size_t c = (size_t)blockIdx.x * kPhaseGroups + threadIdx.x;
     if (threadIdx.x >= (unsigned)kPhaseGroups || c >= nc) return;
     const Fe<F> u = fe_load<F>(u_dev, 0);                      // W(rb*): a final value of phase 1, still on the device
@@ -462,7 +521,7 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         // gate weights w_g = eq(ra, out_g) (layer 0) or alpha eq(rb, out_g) + beta eq(rc, out_g): the previous layer's challenges and
         // alpha / beta are read from its slots, the constants folded into the eq half tables (eq_table.cuh)
         TablePtr eqA, eqB;
-        DevBuf w;
+        DevBuf w, uah, ual, ubh, ubl, uhi, ulo;
         EqBuilder<F> ebA, ebB;                                 // the half tables live until the layer's kernels are enqueued (stream-ordered pool)
         GateWeights gw{};
         static const bool want_table = [] { const char *e = getenv("ZK_GKR_WEIGHT_TABLE"); return e && e[0] == '1'; }();   // measurements / tests
@@ -475,6 +534,13 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
                 unsigned lb2 = 0;
                 ZK_TRY(ebA.halves_dev(ps->slot_ptr(p1 + 3), per, Ly.out_bits, &gw.ah, &gw.al, &gw.lbits, ps->slot_ptr(plk + 2)));   // alpha eq(rb, .)
                 ZK_TRY(ebB.halves_dev(ps->slot_ptr(p2 + 3), per, Ly.out_bits, &gw.bh, &gw.bl, &lb2, ps->slot_ptr(plk + 3)));        // beta eq(rc, .)
+            }
+            // the kernels read them in the products' internal form (UHalves above): high halves as they are stored, low halves times U / R
+            ZK_TRY((halves_to_u<F>(gw.ah, 0, gw.al, Ly.out_bits, gw.lbits, uah, ual)));
+            gw.uah = uah.p; gw.ual = ual.p;
+            if (gw.bh) {
+                ZK_TRY((halves_to_u<F>(gw.bh, 0, gw.bl, Ly.out_bits, gw.lbits, ubh, ubl)));
+                gw.ubh = ubh.p; gw.ubl = ubl.p;
             }
         } else {
             ZK_TRY(w.alloc((ng ? ng : 1) * esz));
@@ -494,8 +560,13 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         TablePtr H1, H0;
         ZK_TRY(alloc_table(F::ID, nk, H1));
         ZK_TRY(alloc_table(F::ID, nk, H0));
-        phase1_tables_kernel<F><<<(unsigned)((nk + kPhaseGroups - 1) / kPhaseGroups), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_left.p, nk, gw, (const uint32_t *)(halves ? Ly.l_out.p : Ly.ord_left.p),
-                                                         (const uint32_t *)Ly.l_right.p, (const uint32_t *)Ly.l_op.p, Wn->dptr, H1->dptr, H0->dptr);
+        {
+            const unsigned grid = (unsigned)((nk + kPhaseGroups - 1) / kPhaseGroups);
+            const uint32_t *st = (const uint32_t *)Ly.st_left.p, *wi = (const uint32_t *)(halves ? Ly.l_out.p : Ly.ord_left.p);
+            const uint32_t *oth = (const uint32_t *)Ly.l_right.p, *ops = (const uint32_t *)Ly.l_op.p;
+            if (gw.uah) phase1_tables_kernel<F, true><<<grid, kBlock, 0, cur_stream()>>>(st, nk, gw, wi, oth, ops, Wn->dptr, H1->dptr, H0->dptr);
+            else phase1_tables_kernel<F, false><<<grid, kBlock, 0, cur_stream()>>>(st, nk, gw, wi, oth, ops, Wn->dptr, H1->dptr, H0->dptr);
+        }
         ZK_HIP(hipGetLastError());
         const zk_table *t1[4] = {Wn, H1.get(), H0.get(), nullptr};
         // the layer's claim (alpha wb + beta wc of the previous link, already in its slot) is absorbed in front of round 0
@@ -508,14 +579,23 @@ template <class F> int sparse_prove(std::vector<LayerDev> &layers, const uint64_
         OtherTable tl{};
         if (k > (uint32_t)kEqSmallBits && !want_table) {           // eq(rb*, .) is only gathered once per gate: half tables do (as for the weights)
             ZK_TRY(ebL.halves_dev(ps->slot_ptr(s1 + 3), per, k, &tl.hi, &tl.lo, &tl.lbits));
+            if (gw.uah) {                                           // both halves times U / R: their product is eq(rb*, .) U (UHalves above)
+                ZK_TRY((halves_to_u<F>(tl.hi, 1, tl.lo, k, tl.lbits, uhi, ulo)));
+                tl.uhi = uhi.p; tl.ulo = ulo.p;
+            }
         } else {
             ZK_TRY((eq_table_dev<F>(ps->slot_ptr(s1 + 3), per, k, eqL)));
             tl.tab = eqL->dptr;
         }
         ZK_TRY(alloc_table(F::ID, nk, Cc));
         ZK_TRY(alloc_table(F::ID, nk, A));
-        phase2_tables_kernel<F><<<(unsigned)((nk + kPhaseGroups - 1) / kPhaseGroups), kBlock, 0, cur_stream()>>>((const uint32_t *)Ly.st_right.p, nk, gw, (const uint32_t *)(halves ? Ly.r_out.p : Ly.ord_right.p),
-                                                         (const uint32_t *)Ly.r_left.p, (const uint32_t *)Ly.r_op.p, tl, u_dev, Cc->dptr, A->dptr);
+        {
+            const unsigned grid = (unsigned)((nk + kPhaseGroups - 1) / kPhaseGroups);
+            const uint32_t *st = (const uint32_t *)Ly.st_right.p, *wi = (const uint32_t *)(halves ? Ly.r_out.p : Ly.ord_right.p);
+            const uint32_t *oth = (const uint32_t *)Ly.r_left.p, *ops = (const uint32_t *)Ly.r_op.p;
+            if (gw.uah) phase2_tables_kernel<F, true><<<grid, kBlock, 0, cur_stream()>>>(st, nk, gw, wi, oth, ops, tl, u_dev, Cc->dptr, A->dptr);
+            else phase2_tables_kernel<F, false><<<grid, kBlock, 0, cur_stream()>>>(st, nk, gw, wi, oth, ops, tl, u_dev, Cc->dptr, A->dptr);
+        }
         ZK_HIP(hipGetLastError());
         const zk_table *t2[4] = {Cc.get(), Wn, A.get(), nullptr};
         const void *cdev[2] = {nullptr, u_dev};
