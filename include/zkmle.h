@@ -338,6 +338,11 @@ int zk_kzg_commit(const zk_table *poly, const zk_g1_bases *g1_powers, uint64_t *
 typedef struct zk_kzg_opening_key zk_kzg_opening_key;
 int zk_kzg_opening_key_new(const zk_g1_bases *g1_powers, zk_kzg_opening_key **out);
 int zk_kzg_opening_key_free(zk_kzg_opening_key *k);
+/* Optional, once per key: zk_g1_bases_precompute on every pre-summed level of at least `min_points` points (0: 2^18), so that
+ * the level MSMs of later openings (multilinear_kzg.rs:96-107) run on one bucket set each.  window_bits = 0: chosen per level.
+ * Costs as zk_g1_bases_precompute, summed over the levels (about as much again as for the setup itself); the proofs are the
+ * same group elements. */
+int zk_kzg_opening_key_precompute(zk_kzg_opening_key *k, int window_bits, size_t min_points);
 int zk_kzg_open(const zk_table *poly, const zk_g1_bases *g1_powers, const zk_kzg_opening_key *key,
                 const uint64_t *opening, size_t nopen, size_t n_g2, uint64_t *evaluation, uint64_t *proofs);
 

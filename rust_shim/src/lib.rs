@@ -80,6 +80,7 @@ pub mod ffi {
         pub fn zk_comm_from_local_group(g: *mut c_void, rank: c_int, out: *mut *mut c_void) -> c_int;
         // once per TrustedSetup: window-shifted copies of g1_powers_of_tau, so that every later commit uses one bucket set (22-bit windows)
         pub fn zk_g1_bases_precompute(b: *mut zk_g1_bases, window_bits: c_int) -> c_int;
+        pub fn zk_kzg_opening_key_precompute(key: *mut c_void, window_bits: c_int, min_points: usize) -> c_int;   // key: zk_kzg_opening_key_new
         pub fn zk_sharded_sumcheck_basic_prove(c: *mut c_void, shard: *const zk_table, absorb_table: c_int, claimed: *mut u64,
                                                rounds: *mut u64, challenges: *mut u64) -> c_int;
         pub fn zk_sharded_sumcheck_gkr_prove(c: *mut c_void, shards: *const *const zk_table, nprod: usize, nfac: usize, claimed: *const u64,

@@ -264,6 +264,13 @@ def test_open_large_levels_on_side_streams_2p21(zk):
     bad = proof.proofs.copy()
     bad[0] = proof.proofs[1]
     assert zk.MultilinearKZG.verify(setup, c, opening, zk.MultilinearKZGProof(proof.evaluation, bad)) is False
+    # window-shifted copies of the setup and of the opening key's large levels (zk_g1_bases_precompute, zk_kzg_opening_key_precompute):
+    # the commitment and every proof point are the same group elements
+    setup.precompute_for_commits()
+    setup.precompute_for_opens(min_points=1 << 16)
+    assert np.array_equal(zk.MultilinearKZG.commit_to_polynomial(poly, setup), c)
+    pre = zk.MultilinearKZG.open_and_prove(poly, setup, opening)
+    assert np.array_equal(pre.proofs, proof.proofs) and np.array_equal(pre.evaluation, proof.evaluation)
 
 
 def test_msm_and_open_on_a_nonblocking_user_stream(zk):

@@ -706,6 +706,14 @@ int zk_kzg_opening_key_new(const zk_g1_bases *g1, zk_kzg_opening_key **out) {
     *out = key.release();
     return ZK_OK;
 }
+int zk_kzg_opening_key_precompute(zk_kzg_opening_key *k, int window_bits, size_t min_points) {
+    if (!k) return ZK_E_ARG;
+    if (min_points == 0) min_points = (size_t)1 << 18;
+    const size_t nbig = k->small_u ? k->small_t0 - 1 : k->nvars;     // levels 1 .. nbig take a plain MSM each (the rest go through the batched pass)
+    for (size_t t = 1; t <= nbig; t++)
+        if (k->level[t] && k->level[t]->n >= min_points) ZK_TRY(zk_g1_bases_precompute(k->level[t], window_bits));
+    return ZK_OK;
+}
 // sum of all the bases of the key's setup = its last pre-summed level (one point), affine
 extern "C++" int zk::kzg_key_total(const zk_kzg_opening_key *k, const zk_g1_bases *g1, uint64_t *out12) {
     const zk_g1_bases *lv = (k && k->nvars >= 1) ? k->level[k->nvars] : g1;

@@ -31,6 +31,7 @@ def _decl():
         "zk_kzg_lagrange_basis": [u64p, sz, C.POINTER(vp)], "zk_kzg_setup_g1": [u64p, sz, C.POINTER(vp)],
         "zk_kzg_commit": [vp, vp, u64p],
         "zk_kzg_opening_key_new": [vp, C.POINTER(vp)], "zk_kzg_opening_key_free": [vp],
+        "zk_kzg_opening_key_precompute": [vp, C.c_int, C.c_size_t],
         "zk_kzg_open": [vp, vp, vp, u64p, sz, sz, u64p, u64p],
         "zk_g2_generator": [u64p], "zk_g2_is_on_curve": [u64p], "zk_g2_add": [u64p, u64p, u64p], "zk_g2_mul_fr": [u64p, u64p, u64p],
         "zk_pairing": [u64p, u64p, u64p], "zk_pairing_product_is_one": [u64p, u64p, sz, C.POINTER(C.c_int)],
@@ -133,6 +134,11 @@ class TrustedSetup:
     def precompute_for_commits(self, window_bits=0):
         """optional, once per setup: window-shifted copies of the G1 powers (zk_g1_bases_precompute); later commits use one bucket set"""
         return self.g1_powers_of_tau.precompute(window_bits)
+
+    def precompute_for_opens(self, window_bits=0, min_points=0):
+        """optional, once per setup: the same for the pre-summed levels of the opening key (zk_kzg_opening_key_precompute): the level MSMs of
+        open_and_prove then use one bucket set each"""
+        L.check(_decl().zk_kzg_opening_key_precompute(self.opening_key(), window_bits, min_points))
 
     @property
     def g2_powers_of_tau(self):
