@@ -720,8 +720,8 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                 if (grp < 3u * (unsigned)a.nprod) {                  // role = (product, point)
                     const unsigned p = grp / 3u, t = grp - 3u * p, b0 = 4u * p * (unsigned)q + i;
                     const Fe<F> lo = exch[b0], hi = exch[b0 + (unsigned)q], lo2 = exch[b0 + 2u * (unsigned)q], hi2 = exch[b0 + 3u * (unsigned)q];
-                    const Fe<F> x = t == 0 ? lo : t == 1 ? hi : fe_add<F>(hi, fe_sub<F>(hi, lo));
-                    const Fe<F> y = t == 0 ? lo2 : t == 1 ? hi2 : fe_add<F>(hi2, fe_sub<F>(hi2, lo2));
+                    const Fe<F> x = t == 0 ? lo : t == 1 ? hi : fe_sub<F>(hi, lo);            // t = 2: the node infinity (sumcheck_kernels.cuh header)
+                    const Fe<F> y = t == 0 ? lo2 : t == 1 ? hi2 : fe_sub<F>(hi2, lo2);
                     const Fe<F> pr = fe_mul<F>(x, y);
                     if (t == 0) wide_add_fe<F>(acc[0], pr);
                     else if (t == 1) wide_add_fe<F>(acc[1], pr);
@@ -750,9 +750,9 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                 if (act) {
                     const unsigned other = grp ^ 1u;             // the other factor of the same product
                     const Fe<F> lo2 = exch[2 * (other * (unsigned)q + i)], hi2 = exch[2 * (other * (unsigned)q + i) + 1];
-                    if ((grp & 1u) == 0) {                       // points 0 and 2: lo lo', (2 hi - lo)(2 hi' - lo')
+                    if ((grp & 1u) == 0) {                       // nodes 0 and infinity: lo lo', (hi - lo)(hi' - lo')
                         wide_add_fe<F>(acc[0], fe_mul<F>(lo, lo2));
-                        wide_add_fe<F>(acc[2], fe_mul<F>(fe_add<F>(hi, fe_sub<F>(hi, lo)), fe_add<F>(hi2, fe_sub<F>(hi2, lo2))));
+                        wide_add_fe<F>(acc[2], fe_mul<F>(fe_sub<F>(hi, lo), fe_sub<F>(hi2, lo2)));
                     } else {                                     // point 1: hi hi'
                         wide_add_fe<F>(acc[1], fe_mul<F>(hi, hi2));
                     }

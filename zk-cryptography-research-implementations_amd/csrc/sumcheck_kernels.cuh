@@ -6,7 +6,13 @@
 // SumPolynomial::partial_evaluate (sum_polynomial.rs:40-53) folds every table again.
 // Here one kernel per round streams every table once:
 //   round_evals_kernel        evals e(t) = sum_i sum_p prod_f X_t[p][f][i],  X_t = lo + t (hi - lo),
-//                             t = 0..NFAC  (t-steps are additions only)
+//                             t = 0..NFAC  (t-steps are additions only).  Products of TWO factors (every GKR round) use the
+//                             nodes 0, 1 and infinity instead (r3): e(inf) = the X^2 coefficient = sum prod_f (hi - lo): one
+//                             subtraction per factor where the node 2 took two operations, and nothing at all for a product
+//                             whose second factor is constant (its X^2 coefficient is zero).  The reference interpolates the
+//                             round polynomial from evaluations (sumcheck_gkr_protocol.rs:46-50) and sends COEFFICIENTS: the
+//                             same polynomial from other nodes is the same message (kSecondNodeInfinity, zkmle_sumcheck.hip
+//                             sumcheck_basis).
 //   fold_round_evals_kernel   folds every table by the previous challenge AND produces the next
 //                             round's e(t) from the folded values in the same pass.
 // Algorithmic traffic of the fused kernel on NT = NPROD*NFAC tables of 2^m entries:
@@ -67,6 +73,12 @@ __device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const 
         v[f] = lo[f];
         d[f] = fe_sub<F>(hi[f], lo[f]);
     }
+    if constexpr (NFAC == 2) {                               // nodes 0, 1, infinity (header)
+        wide_add_fe<F>(acc[0], fe_mul<F>(lo[0], lo[1]));
+        if (!skip1) wide_add_fe<F>(acc[1], fe_mul<F>(hi[0], hi[1]));
+        wide_add_fe<F>(acc[2], fe_mul<F>(d[0], d[1]));
+        return;
+    }
 #pragma unroll
     for (int t = 0; t <= NFAC; t++) {
         if (!(skip1 && t == 1)) {                            // the point 1 is derived from the running claim (dev_transcript.cuh)
@@ -86,8 +98,8 @@ __device__ __forceinline__ void accumulate_terms(const Fe<F> (&lo)[NFAC], const 
 // A round evaluation is a sum of products; sum_i mont(a_i, b_i) = mont-reduce(sum_i a_i b_i), so the lane accumulates the raw
 // double-width products (L^2 multiply-adds each instead of 2 L^2, no conversion back to 32-bit limbs) and the workgroup reduces the
 // total once.  The accumulator keeps 2 L + 1 limbs of 29 bits in 32-bit words; every product adds less than 2^29 to a limb, so the
-// carries are propagated every 6 products.  Operands may be any representative below 2^(29 L - 3): the points 0, 1, 2 use lo, hi
-// and 2 hi - lo + 4 p without a modular reduction.
+// carries are propagated every 6 products.  Operands may be any representative below 2^(29 L - 3): the nodes 0, 1, infinity use lo, hi
+// and hi - lo + 4 p without a modular reduction.
 template <class F> struct ProdConsts;            // c1 = 2^(29 L + SH) mod p, c2 = 2^(58 L + SH) mod p, 29-bit limbs
 template <> struct ProdConsts<Fr381> {
     static ZK_HD uint32_t c1(int i) { constexpr uint32_t t[9] = {0x1ffff72bu, 0x000046a7u, 0x1f5f3540u, 0x0ce3021cu, 0x118f3661u, 0x008176cbu, 0x054e487cu, 0x102e8190u, 0x001e092eu}; return t[i]; }
@@ -147,14 +159,15 @@ template <class F> __device__ __forceinline__ void prod_carry(ProdAcc<F> &acc) {
 // the three (or two) evaluation terms of one product of two factors at one pair index
 // SKIP1 (the point 1 is derived from the running claim, dev_transcript.cuh kDerive1): TWO accumulators instead of three -- 19 VGPRs less
 // across the loop, which is what keeps the first-round kernel under 128 VGPRs (4 waves per SIMD instead of 3; r3).  acc[0] = e(0),
-// acc[NACC - 1] = e(2), acc[1] = e(1) when it is evaluated.
+// acc[NACC - 1] = e(infinity), acc[1] = e(1) when it is evaluated.  `const2`: the second factor is the constant (lo[1] = hi[1]): the product is
+// linear in X, nothing to add to e(infinity).
 template <class F, bool SKIP1>
-__device__ __forceinline__ void accumulate_terms_lazy(const Fe<F> (&lo)[2], const Fe<F> (&hi)[2], ProdAcc<F> (&acc)[SKIP1 ? 2 : 3]) {
+__device__ __forceinline__ void accumulate_terms_lazy(const Fe<F> (&lo)[2], const Fe<F> (&hi)[2], ProdAcc<F> (&acc)[SKIP1 ? 2 : 3], bool const2) {
     const Ufe<F> l0 = u_from_limbs32<F>(lo[0]), l1 = u_from_limbs32<F>(lo[1]);
     const Ufe<F> h0 = u_from_limbs32<F>(hi[0]), h1 = u_from_limbs32<F>(hi[1]);
     prod_accumulate<F>(acc[0], l0, l1);
     if constexpr (!SKIP1) prod_accumulate<F>(acc[1], h0, h1);
-    prod_accumulate<F>(acc[SKIP1 ? 1 : 2], uadd<F>(h0, usub<F>(h0, l0)), uadd<F>(h1, usub<F>(h1, l1)));    // X(2) = 2 hi - lo (+ 4 p)
+    if (!const2) prod_accumulate<F>(acc[SKIP1 ? 1 : 2], usub<F>(h0, l0), usub<F>(h1, l1));             // X^2 coefficient: (hi - lo + 4 p)(hi' - lo' + 4 p)
 }
 // 2 L + 1 normalized 29-bit limbs -> 2 N + 2 saturated 32-bit words
 template <class F> struct ProdWide {
@@ -271,7 +284,7 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
                     lo[f] = fe_load<F>(tabs.in[p * 2 + f], i);
                     hi[f] = fe_load<F>(tabs.in[p * 2 + f], i + half);
                 }
-                accumulate_terms_lazy<F, SKIP1>(lo, hi, pacc);
+                accumulate_terms_lazy<F, SKIP1>(lo, hi, pacc, tabs.in[p * 2 + 1] == nullptr);
                 if (++pending == kProdCarryEvery) {
                     pending = 0;
 #pragma unroll
@@ -334,7 +347,7 @@ __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs,
                     fe_store<F>(dst, i, lo[f]);
                     fe_store<F>(dst, i + q, hi[f]);
                 }
-                accumulate_terms_lazy<F, SKIP1>(lo, hi, pacc);
+                accumulate_terms_lazy<F, SKIP1>(lo, hi, pacc, tabs.in[p * 2 + 1] == nullptr);
                 if (++pending == kProdCarryEvery) {
                     pending = 0;
 #pragma unroll
@@ -379,7 +392,7 @@ __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables 
 // The same round for SHORT tables of products of two factors.  Below ~2^15 pair indices the launch above does not fill the
 // device and lasts as long as one lane's chain of products (14 for two products); here a wave takes ONE table for 64 consecutive
 // pair indices (2 fold products per lane), the factors of a product meet in LDS, and the even wave of a product evaluates the
-// points 0 and 2, the odd one the point 1: a chain of 4.  blockDim = 64 * ntab (ntab <= 8), grid = q / 64 = the number of partials.
+// points 0 and infinity, the odd one the point 1: a chain of 4.  blockDim = 64 * ntab (ntab <= 8), grid = q / 64 = the number of partials.
 constexpr size_t kSplitRoundMaxQ = (size_t)1 << 15;
 template <class F>
 __global__ void __launch_bounds__(512) fold_round_evals_split_kernel(SumPolyTables tabs, size_t q, Fe<F> r, void *__restrict__ partials,
@@ -409,7 +422,7 @@ __global__ void __launch_bounds__(512) fold_round_evals_split_kernel(SumPolyTabl
     const Fe<F> lo2 = exch[2 * ((k ^ 1u) * 64 + lane)], hi2 = exch[2 * ((k ^ 1u) * 64 + lane) + 1];
     if ((k & 1u) == 0) {
         wide_add_fe<F>(acc[0], fe_mul<F>(lo, lo2));
-        wide_add_fe<F>(acc[2], fe_mul<F>(fe_add<F>(hi, fe_sub<F>(hi, lo)), fe_add<F>(hi2, fe_sub<F>(hi2, lo2))));
+        wide_add_fe<F>(acc[2], fe_mul<F>(fe_sub<F>(hi, lo), fe_sub<F>(hi2, lo2)));      // node infinity: the X^2 coefficient (header)
     } else if (!skip1) {
         wide_add_fe<F>(acc[1], fe_mul<F>(hi, hi2));
     }

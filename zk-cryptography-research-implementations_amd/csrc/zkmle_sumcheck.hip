@@ -814,6 +814,14 @@ template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int np
     return ZK_OK;
 }
 
+// The public evaluation entry points return e(0), e(1), e(2) (include/zkmle.h); the two-factor kernels produce e(0), e(1), e(inf) = c2:
+// e(2) = c0 + 2 c1 + 4 c2 = 2 (e(1) + e(inf)) - e(0).
+template <class F> void evals_node2_from_infinity(uint64_t *evals) {
+    const size_t L64 = F::N / 2;
+    const Fe<F> e0 = load_el<F>(evals), e1 = load_el<F>(evals + L64), ei = load_el<F>(evals + 2 * L64);
+    const Fe<F> s = fe_add<F>(e1, ei);
+    store_el<F>(evals + 2 * L64, fe_sub<F>(fe_add<F>(s, s), e0));
+}
 template <class F> int round_evals(const zk_table *const *tables, size_t nprod, size_t nfac, uint64_t *out) {
     const size_t esz = 4 * F::N;
     size_t len = tables[0]->len;
@@ -831,12 +839,16 @@ template <class F> int round_evals(const zk_table *const *tables, size_t nprod, 
     finish_sums_kernel<F><<<1, kBlock, 0, cur_stream()>>>(part, (size_t)grid, (int)npts, res);
     ZK_HIP(hipGetLastError());
     ZK_HIP(zk::memcpy_on_stream(out, res, esz * npts, hipMemcpyDeviceToHost));
+    if (nfac == 2) evals_node2_from_infinity<F>(out);
     return ZK_OK;
 }
 
 // The interpolation nodes of the GKR sumcheck are always 0..d (sumcheck_gkr_protocol.rs:46-48), so the Lagrange basis
 // (d + 1 host inversions, ~0.15 ms) is built once per (field, d) and kept: Montgomery form, then canonical integers
 // (FinishArgs::basis).
+// d = 2 (every GKR round: products of two factors): the kernels evaluate at 0, 1 and INFINITY -- e(inf) = the X^2 coefficient
+// (sumcheck_kernels.cuh header) -- and the matrix below turns those into the coefficients: c0 = e0, c1 = e1 - e0 - e(inf), c2 = e(inf).
+// The round message is the coefficient vector of the same polynomial the reference interpolates from e(0), e(1), e(2).
 template <class F> const std::vector<Fe<F>> &sumcheck_basis(size_t npts) {
     static std::mutex mu;
     static std::map<size_t, std::vector<Fe<F>>> cache;
@@ -845,7 +857,11 @@ template <class F> const std::vector<Fe<F>> &sumcheck_basis(size_t npts) {
     if (it != cache.end()) return it->second;
     std::vector<Fe<F>> xs(npts);
     for (size_t i = 0; i < npts; i++) xs[i] = fe_from_u64<F>(i);
-    const std::vector<std::vector<Fe<F>>> basis = lagrange_basis_matrix<F>(xs);
+    std::vector<std::vector<Fe<F>>> basis = lagrange_basis_matrix<F>(xs);
+    if (npts == 3) {                                           // basis[i][d] = the weight of evaluation i in coefficient d
+        const Fe<F> one = fe_one<F>(), zero = fe_zero<F>(), minus = fe_sub<F>(zero, one);
+        basis = {{one, minus, zero}, {zero, one, zero}, {zero, minus, one}};
+    }
     std::vector<Fe<F>> flat(2 * npts * npts);
     for (size_t i = 0; i < npts; i++)
         for (size_t d = 0; d < npts; d++) {
@@ -1359,6 +1375,7 @@ int zk_sumpoly_fold_round_evals(const zk_table *const *in, zk_table *const *out,
             finish_sums_kernel<F><<<1, kBlock, 0, cur_stream()>>>(part, (size_t)grid, (int)npts, res);
             ZK_HIP(hipGetLastError());
             ZK_HIP(zk::memcpy_on_stream(out_evals, res, esz * npts, hipMemcpyDeviceToHost));
+            if (nfac == 2) evals_node2_from_infinity<F>(out_evals);
         }
     });
     for (size_t k = 0; k < nprod * nfac; k++) out[k]->len = len / 2;
