@@ -723,7 +723,8 @@ def baseline_configs(zk, args):
     def busy():                                             # ~8 ms of GPU work in front of the 400 timed 10-us launches
         for _ in range(60):
             _lib.check(L.zk_mle_fold(big._h, 0, _lib.p64(r), big_dst._h, stream))
-    fold_ms = event_time_ms(lambda: _lib.check(L.zk_mle_fold(poly._h, 0, _lib.p64(r), dst._h, stream)), 400, warm=200, blocker=busy)
+    fold_ms = min(event_time_ms(lambda: _lib.check(L.zk_mle_fold(poly._h, 0, _lib.p64(r), dst._h, stream)), 400, warm=200, blocker=busy)
+                  for _ in range(3))                    # the smallest of three: one run on a loaded host read 156 us for this 11-us launch
     del big, big_dst
     prover = zk.Prover.init(0, poly)
     prover.prove()
