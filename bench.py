@@ -827,10 +827,10 @@ def baseline_configs(zk, args):
                        "what": "4 tables of 2^22 entries (2 products x 2 factors), HIP events over 200 back-to-back enqueue-only launches",
                        "fold_round_evals_kernel": {"us": fre_ms * 1e3, "GBps": fre_bytes / (fre_ms * 1e-3) / 1e9, "frac": fre_bytes / (fre_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                                    "algorithmic_bytes": fre_bytes, "field_mul_per_s": 12.0 * q / (fre_ms * 1e-3),
-                                                   "field_mul_per_pair_index": "8 fold products + 4 evaluation products (the point 1 is derived)"},
+                                                   "field_mul_per_pair_index": "8 fold products + 4 evaluation products (nodes 0 and infinity; the node 1 is derived)"},
                        "round_evals_kernel": {"us": re_ms * 1e3, "GBps": re_bytes / (re_ms * 1e-3) / 1e9, "frac": re_bytes / (re_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                               "algorithmic_bytes": re_bytes, "field_mul_per_s": 6.0 * (ng // 2) / (re_ms * 1e-3),
-                                              "field_mul_per_pair_index": "6 evaluation products (points 0, 1, 2 of 2 products)"}},
+                                              "field_mul_per_pair_index": "6 evaluation products (nodes 0, 1, infinity of 2 products)"}},
                    "post_check": {"sparse_verifier_accepts": bool(ok)},
                    "note": "prove_s includes the sequential host Keccak absorb of the 2^22-entry output layer; circuit_compile_s is paid once per circuit"}
     return out
