@@ -23,9 +23,29 @@ int launch_foldk(const void *in, void *out, size_t n, int k, const void *const *
     a.in = in; a.out = out; a.n = n;
     for (int i = 0; i < k; i++) a.r[i] = rp[i];
     a.partials = m_next ? part : nullptr;
+    const MultiFin f = (FIN && fin && m_next) ? *fin : MultiFin{};
+    if constexpr (FIN) {
+        // an output of fewer than 4 waves per SIMD (1024 workgroups) with one lane per output: two lanes per output (foldk_seg_sums_split2_kernel)
+        static const bool split2_on = [] { const char *e = getenv("ZK_FOLD_SPLIT2"); return !(e && e[0] == '0'); }();
+        const size_t seglen = n >> m_next, half_block = kBlock / 2;
+        if (split2_on && k >= 5 && m_next && seglen >= half_block && n / kBlock < (size_t)multi_blocks()) {
+            size_t b = seglen / half_block;                      // powers of two: seglen is a multiple of bps * kBlock / 2
+            const size_t cap = (size_t)multi_blocks() >> m_next;
+            while (b > cap && b > 1) b >>= 1;                    // stays a power of two whatever ZK_MULTI_BLOCKS says
+            a.bps = (unsigned)b;
+            const unsigned grid2 = a.bps << m_next;
+            if (k == 5) foldk_seg_sums_split2_kernel<F, 5, true><<<grid2, kBlock, 0, cur_stream()>>>(a, f);
+            else if (k == 6) foldk_seg_sums_split2_kernel<F, 6, true><<<grid2, kBlock, 0, cur_stream()>>>(a, f);
+            else if (k == 7) foldk_seg_sums_split2_kernel<F, 7, true><<<grid2, kBlock, 0, cur_stream()>>>(a, f);
+            else if (k == 8) foldk_seg_sums_split2_kernel<F, 8, true><<<grid2, kBlock, 0, cur_stream()>>>(a, f);
+            else return ZK_E_ARG;
+            ZK_HIP(hipGetLastError());
+            if (bps_out) *bps_out = a.bps;
+            return ZK_OK;
+        }
+    }
     a.bps = multi_bps(n >> m_next, m_next);
     const unsigned grid = a.bps << m_next;
-    const MultiFin f = (FIN && fin && m_next) ? *fin : MultiFin{};
     switch (k) {
         case 1: foldk_seg_sums_kernel<F, 1, FIN><<<grid, kBlock, 0, cur_stream()>>>(a, f); break;
         case 2: foldk_seg_sums_kernel<F, 2, FIN><<<grid, kBlock, 0, cur_stream()>>>(a, f); break;

@@ -405,6 +405,67 @@ template <class F, int K, bool FIN = false> __global__ void __launch_bounds__(kB
     if (have) fe_store<F>(a.partials, blockIdx.x, tot);
 }
 
+// The same pass with TWO lanes per output: a pass whose output is short for the chip (2^24 -> 2^17: 512 workgroups of one lane per output are two
+// waves per SIMD, and the pass is as much multiply-adds as bytes: 106-108 us where its bytes alone are ~91) keeps four waves per SIMD this way.
+// Lane part q sums the inputs i = q 2^(K-1) ..., the upper part hands its (reduced) half to the lower one through LDS.  Same weights, same exact sum.
+// a.bps counts workgroups of kBlock / 2 outputs per segment; seglen is a multiple of a.bps * kBlock / 2 (fold_multi.h).
+template <class F, int K, bool FIN = false> __global__ void __launch_bounds__(kBlock) foldk_seg_sums_split2_kernel(FoldKArgs a, MultiFin fin) {
+    static_assert(K >= 4 && K <= 8, "2^(K-1) inputs per lane");
+    constexpr int kOut = kBlock / 2, kPer = (1 << K) / 2;
+    __shared__ Wide<F> sh[kBlock / 64];
+    __shared__ Ufe<F> sw[1 << K];
+    __shared__ Fe<F> parts[kOut];
+    const unsigned nseg = gridDim.x / a.bps, seg = blockIdx.x / a.bps, bq = blockIdx.x % a.bps;
+    const size_t seglen = a.n / nseg, base = (size_t)seg * seglen, stride = (size_t)a.bps * kOut;
+    if (FIN && fin.trace && blockIdx.x == 0 && threadIdx.x == 0) fin.trace[0] = wall_clock64();
+    if (threadIdx.x < (1u << K)) {
+        Fe<F> w = fe_one<F>();
+#pragma unroll
+        for (int l = 0; l < K; l++) {
+            const Fe<F> r = fe_load<F>(a.r[l], 0);
+            w = fe_mul<F>(w, ((threadIdx.x >> (K - 1 - l)) & 1u) ? r : fe_sub<F>(fe_one<F>(), r));
+        }
+        sw[threadIdx.x] = u_reduce_once<F>(u_from_std<F>(w));
+    }
+    __syncthreads();
+    const unsigned q = threadIdx.x / kOut, jj = threadIdx.x % kOut;
+    Wide<F> acc[1] = {wide_zero<F>()};
+    for (size_t t = (size_t)bq * kOut + jj; t < seglen; t += stride) {       // the same trip count for every lane of the workgroup
+        const size_t j = base + t;
+        RawAcc<F> ra;
+#pragma unroll
+        for (int c = 0; c < 2 * UParams<F>::L; c++) ra.c[c] = 0;
+#pragma unroll 1
+        for (int i0 = 0; i0 < kPer; i0 += kRawCarryEvery) {
+            Fe<F> x[kRawCarryEvery];
+#pragma unroll
+            for (int i = 0; i < kRawCarryEvery; i++) x[i] = fe_load<F>(a.in, j + (size_t)(q * kPer + i0 + i) * a.n);
+#pragma unroll
+            for (int i = 0; i < kRawCarryEvery; i++) raw_mul_add<F>(ra, u_from_limbs32<F>(x[i]), sw[q * kPer + i0 + i]);
+            raw_normalize<F>(ra);
+        }
+        Fe<F> v = u_to_limbs32<F>(u_reduce_once<F>(raw_mont_reduce<F>(ra)));
+        if (q == 1) parts[jj] = v;
+        __syncthreads();
+        if (q == 0) {
+            v = fe_add<F>(v, parts[jj]);
+            fe_store<F>(a.out, j, v);
+            wide_add_fe<F>(acc[0], v);
+        }
+        __syncthreads();
+    }
+    if (a.partials == nullptr) return;
+    Fe<F> tot;
+    const bool have = block_reduce_wide<F, 1>(acc, sh, tot);
+    if constexpr (FIN) {
+        if (fin.counter) {
+            if (threadIdx.x < 64) multi_finish_in_producer<F>(fin, a.bps, tot);
+            return;
+        }
+    }
+    if (have) fe_store<F>(a.partials, blockIdx.x, tot);
+}
+
 // A pass with a SHORT output (n <= 2^13 entries: the last one before a one-workgroup tail) has too few outputs to fill the chip with one
 // lane per output -- 2^11 outputs from 2^17 inputs are 8 workgroups whose lanes read 64 inputs one chunk after the other, 34 us for 4 MB
 // (r3 trace).  Here kFoldSplit lanes share an output: lane part q sums inputs i = q * 2^K / kFoldSplit ... with the same weights and
