@@ -98,6 +98,15 @@ def main():
     checked += 1
     if not zk.gkr.sparse_verify(0, rows2, [lg2] * 2, proof2, x2):
         bad.append(["sparse_gkr_verify_skewed", lg2])
+    # the other fields through the same paths (the half tables in the products' internal form have a per-field limb count: 9 / 14 limbs of 29 bits)
+    for fld in (1, 2, 3):
+        x3 = rand_table(fld, n2, 4400 + fld)
+        proof3 = zk.gkr.sparse_prove(fld, rows2, [lg2] * 2, x3)
+        for arr in (proof3.circuit_output, proof3.coeffs, proof3.challenges, proof3.wb_evals, proof3.wc_evals):
+            h.update(np.ascontiguousarray(arr).tobytes())
+        checked += 1
+        if not zk.gkr.sparse_verify(fld, rows2, [lg2] * 2, proof3, x3):
+            bad.append(["sparse_gkr_verify_field", fld])
     print(json.dumps({"checked": checked, "mismatches": bad, "sparse_gkr_digest": h.hexdigest(), "env": {k: v for k, v in os.environ.items() if k.startswith("ZK_")}}), flush=True)
 
 
