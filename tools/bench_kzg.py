@@ -36,7 +36,11 @@ for lg in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "16,20").split
         proof = zk.MultilinearKZG.open_and_prove(poly, setup, point)
         sync(); opens.append(time.time() - t0)
     t_open = min(opens)
-    pre = {}
+    t0 = time.time()
+    verified = bool(zk.MultilinearKZG.verify(setup, c, point, proof))          # :131-158, pairings on the host
+    t_verify = time.time() - t0
+    assert verified, "the opening that was timed does not verify"
+    pre = {"verified": verified, "verify_s": t_verify}
     if len(sys.argv) > 2 and sys.argv[2] == "pre":          # the same on window-shifted copies of the setup and of the key's large levels
         t0 = time.time(); setup.precompute_for_commits(); setup.precompute_for_opens(); sync(); pre["precompute_s"] = time.time() - t0
         zk.MultilinearKZG.commit_to_polynomial(poly, setup)
