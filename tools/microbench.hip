@@ -103,6 +103,15 @@ template <class F> __global__ void k_stream3(const void *in, void *out, size_t h
         zk::fe_store<F>(out, i, a);
     }
 }
+// the same three streams with 16 B per lane, fully coalesced (n16 = output length in uint4): is the 32-byte-per-lane pattern what the fold pays for?
+__global__ void k_stream3_16(const uint4 *in, uint4 *out, size_t n16) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        uint4 a = in[i], b = in[i + n16];
+        a.x ^= b.x; a.y ^= b.y; a.z ^= b.z; a.w ^= b.w;
+        out[i] = a;
+    }
+}
 __global__ void k_copy16(const uint4 *in, uint4 *out, size_t n) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
@@ -258,6 +267,12 @@ int main(int argc, char **argv) {
             RUN_V(1, false, 256) RUN_V(1, false, 512) RUN_V(1, false, 1024) RUN_V(1, false, 128) RUN_V(1, false, 64)
             RUN_V(2, false, 256) RUN_V(4, false, 256) RUN_V(2, false, 128) RUN_V(2, false, 512)
             RUN_V(1, true, 256) RUN_V(2, true, 256)
+        }
+        for (int grid : {2048, 8192, 65536}) {
+            float ms3 = time_ms([&] { k_stream3_16<<<grid, 256>>>((const uint4 *)in, (uint4 *)out, half * 2); }, 10);
+            printf("{\"kernel\": \"stream3_coalesced16\", \"grid\": %d, \"ms\": %.4f, \"GBps\": %.1f}\n", grid, ms3, 96.0 * half / (ms3 * 1e-3) / 1e9);
+            float ms3a = time_ms([&] { k_stream3<zk::Fr381><<<grid, 256>>>(in, out, half); }, 10);
+            printf("{\"kernel\": \"stream3_aos32\", \"grid\": %d, \"ms\": %.4f, \"GBps\": %.1f}\n", grid, ms3a, 96.0 * half / (ms3a * 1e-3) / 1e9);
         }
         float ms = time_ms([&] { k_copy16<<<2048, 256>>>((const uint4 *)in, (uint4 *)out, half * 2); }, 10);
         printf("{\"kernel\": \"copy16\", \"ms\": %.4f, \"GBps\": %.1f}\n", ms, 2.0 * 32 * half / (ms * 1e-3) / 1e9);
