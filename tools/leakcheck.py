@@ -27,6 +27,9 @@ def job():
     c = zk.MultilinearKZG.commit_to_polynomial(p12, setup)
     pr = zk.MultilinearKZG.open_and_prove(p12, setup, taus)
     assert zk.MultilinearKZG.verify(setup, c, taus, pr)
+    setup.precompute_for_commits()                       # window-shifted copies of the setup and of the opening key's levels: freed with their handles
+    setup.precompute_for_opens(min_points=1 << 8)
+    assert np.array_equal(zk.MultilinearKZG.open_and_prove(p12, setup, taus).proofs, pr.proofs)
 
 
 for _ in range(3):
