@@ -167,7 +167,10 @@ __device__ __forceinline__ void accumulate_terms_lazy(const Fe<F> (&lo)[2], cons
     const Ufe<F> h0 = u_from_limbs32<F>(hi[0]), h1 = u_from_limbs32<F>(hi[1]);
     prod_accumulate<F>(acc[0], l0, l1);
     if constexpr (!SKIP1) prod_accumulate<F>(acc[1], h0, h1);
-    if (!const2) prod_accumulate<F>(acc[SKIP1 ? 1 : 2], usub<F>(h0, l0), usub<F>(h1, l1));             // X^2 coefficient: (hi - lo + 4 p)(hi' - lo' + 4 p)
+    // X^2 coefficient: (hi - lo + 4 p)(hi' - lo' + 4 p).  With a constant second factor the second difference is 4 p and the product a multiple of p:
+    // skipped where the skip is free (SKIP1: the variant every large round runs); the three-accumulator variant keeps the loop branch-free
+    // (the branch cost it 13 VGPRs and its fourth wave per SIMD).
+    if (!SKIP1 || !const2) prod_accumulate<F>(acc[SKIP1 ? 1 : 2], usub<F>(h0, l0), usub<F>(h1, l1));
 }
 // 2 L + 1 normalized 29-bit limbs -> 2 N + 2 saturated 32-bit words
 template <class F> struct ProdWide {
