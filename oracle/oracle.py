@@ -428,6 +428,34 @@ def gkr_prove(field, layers, inputs):
     return proof
 
 
+def gkr_prove_wide(field, rows, out_bits, inputs):
+    """gkr_protocol::prove for layers of any width, from the definition, linear in the gates (gkr_wide.c).  rows[l]: uint64 array
+    (ngates, 4) of (left, right, out, op) -- the layout the product's sparse prover takes; out_bits[l] = log2 of layer l's width."""
+    x = _arr(field, inputs)
+    L = x.shape[1]
+    nl = len(rows)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(r, np.uint64).reshape(-1, 4) for r in rows]))
+    counts = (C.c_size_t * nl)(*[len(r) for r in rows])
+    ob = (C.c_uint32 * nl)(*[int(b) for b in out_bits])
+    widths = [1 << int(b) for b in out_bits] + [x.shape[0]]
+    rounds = [2 * (widths[l + 1].bit_length() - 1) for l in range(nl)]
+    tot = sum(rounds)
+    proof = dict(
+        circuit_output=np.zeros((widths[0], L), np.uint64), claimed_sum=np.zeros(L, np.uint64),
+        layer_claims=np.zeros((nl, L), np.uint64), coeffs=np.zeros((max(tot, 1), 3, L), np.uint64),
+        challenges=np.zeros((max(tot, 1), L), np.uint64), wb_evals=np.zeros((max(nl - 1, 1), L), np.uint64),
+        wc_evals=np.zeros((max(nl - 1, 1), L), np.uint64), output_challenges=np.zeros((int(out_bits[0]), L), np.uint64))
+    _chk(lib().orc_gkr_prove_wide(field, flat.ctypes.data_as(C.c_void_p), counts, C.c_size_t(nl), ob, _p(x), C.c_size_t(x.shape[0]),
+                                  _p(proof["circuit_output"]), _p(proof["claimed_sum"]), _p(proof["layer_claims"]), _p(proof["coeffs"]),
+                                  _p(proof["challenges"]), _p(proof["wb_evals"]), _p(proof["wc_evals"]), _p(proof["output_challenges"])),
+         "gkr::prove (wide)")
+    proof["coeffs"] = proof["coeffs"][:tot]
+    proof["challenges"] = proof["challenges"][:tot]
+    proof["wb_evals"] = proof["wb_evals"][: nl - 1]
+    proof["wc_evals"] = proof["wc_evals"][: nl - 1]
+    return proof
+
+
 def gkr_verify(field, layers, proof, inputs):
     gates, counts = _circuit(layers)
     x = _arr(field, inputs)

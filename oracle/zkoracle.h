@@ -157,6 +157,13 @@ int orc_gkr_prove(int field, const orc_gate *gates, const size_t *gate_counts, s
                   const uint64_t *inputs, size_t ninputs, uint64_t *circuit_output,
                   size_t *output_len, uint64_t *claimed_sum, uint64_t *layer_claims,
                   uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals);
+/* gkr_protocol::prove for layers of any width, linear in the number of gates, straight from the definition of the layer polynomial
+ * (gkr_wide.c): layer l has 2^out_bits[l] outputs and reads the 2^out_bits[l+1] wires of the next layer (the ninputs inputs for the last);
+ * out_bits[0] >= 1 output challenges; rounds(l) = 2 * log2(width of layer l + 1).  Same flattened proof as orc_gkr_prove. */
+int orc_gkr_prove_wide(int field, const orc_gate *gates, const size_t *gate_counts, size_t nlayers, const uint32_t *out_bits,
+                       const uint64_t *inputs, size_t ninputs, uint64_t *circuit_output, uint64_t *claimed_sum,
+                       uint64_t *layer_claims, uint64_t *coeffs, uint64_t *challenges, uint64_t *wb_evals, uint64_t *wc_evals,
+                       uint64_t *output_challenges);
 /* gkr_protocol::verify :146 ; 1/0 */
 int orc_gkr_verify(int field, const orc_gate *gates, const size_t *gate_counts, size_t nlayers,
                    const uint64_t *inputs, size_t ninputs, const uint64_t *circuit_output,

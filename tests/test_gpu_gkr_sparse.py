@@ -202,3 +202,54 @@ def test_skewed_wiring_bit_identical_to_generalised_dense_model(zk):
     assert zk.to_ints(f, proof.challenges) == want["challenges"]
     assert zk.to_ints(f, proof.wb_evals) == want["wb"] and zk.to_ints(f, proof.wc_evals) == want["wc"]
     assert zk.gkr.sparse_verify(f, rows, out_bits, proof, x) is True
+
+
+def _layers(wiring, lg, depth, seed):
+    n = 1 << lg
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(depth):
+        g = np.zeros((n, 4), np.uint64)
+        if wiring == "random":
+            g[:, 0] = rng.integers(0, n, n); g[:, 1] = rng.integers(0, n, n)
+        elif wiring == "regular":
+            g[:, 0] = (2 * np.arange(n)) % n; g[:, 1] = (2 * np.arange(n) + 1) % n
+        else:                                                   # skewed: half of the gates read ONE left wire, a quarter ONE right wire
+            g[:, 0] = rng.integers(0, n, n); g[:, 1] = rng.integers(0, n, n)
+            g[: n // 2, 0] = int(rng.integers(0, n)); g[n // 2: 3 * n // 4, 1] = int(rng.integers(0, n))
+        g[:, 2] = rng.permutation(n) if wiring == "skewed" else np.arange(n)
+        g[:, 3] = rng.integers(0, 2, n)
+        if wiring != "regular":                                 # some outputs fed by several gates, some by none (+=, arithmetic_circuit.rs:96)
+            g[: n // 16, 2] = g[n // 16: n // 8, 2]
+        rows.append(g)
+    return rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,wiring,lg", [(0, "random", 10), (0, "regular", 10), (0, "skewed", 10), (2, "random", 10), (2, "skewed", 10),
+                                             (0, "random", 13), (0, "regular", 13), (0, "skewed", 13), (2, "random", 13), (2, "regular", 13),
+                                             (0, "random", 16), (0, "regular", 16), (0, "skewed", 16), (2, "random", 16),
+                                             (0, "random", 18), (2, "skewed", 18)])
+def test_mid_size_proofs_bit_identical_to_the_linear_time_oracle(zk, field, wiring, lg):
+    """The regime between the dense models (<= 2^6 wires) and config 4 (2^22), where every multi-workgroup path of the sparse prover runs --
+    multi-pass table kernels, eq outer products, grid-wide fused rounds with the exchange in their last workgroup, split rounds, tails -- against
+    an oracle that shares none of that: oracle/gkr_wide.c sums every round polynomial gate by gate from the definition of f(b, c)
+    (gkr_protocol.rs:57-143, utils.rs:8-68; pinned on small shapes by the dense models, tests/test_oracle_gkr_wide.py).  Depth 3, 2^lg
+    gates per layer; the WHOLE proof: every coefficient, challenge, layer claim, wb / wc, the output challenges."""
+    depth, n = 3, 1 << lg
+    rows = _layers(wiring, lg, depth, 0x5EED0400 + lg + 7 * field)
+    out_bits = [lg] * depth
+    x = zk.MultilinearPolynomial.random(field, n, 0x5EED0004 + lg).evaluated_values
+    x[:4] = zk.from_ints(field, [0, 1, O.modulus(field) - 1, 2])
+    want = O.gkr_prove_wide(field, rows, out_bits, x)
+    proof = zk.gkr.sparse_prove(field, rows, out_bits, x)
+    assert np.array_equal(proof.circuit_output, want["circuit_output"])
+    assert np.array_equal(proof.output_challenges, want["output_challenges"])
+    assert np.array_equal(proof.layer_claims, want["layer_claims"])
+    assert np.array_equal(proof.coeffs, want["coeffs"])
+    assert np.array_equal(proof.challenges, want["challenges"])
+    assert np.array_equal(proof.wb_evals, want["wb_evals"]) and np.array_equal(proof.wc_evals, want["wc_evals"])
+    assert np.array_equal(np.asarray(proof.claimed_sum).reshape(-1), want["claimed_sum"])
+    circuit = zk.gkr.SparseCircuit(rows, out_bits, n)           # the compiled-circuit path: the same bytes
+    again = zk.gkr.sparse_prove(field, None, None, x, circuit=circuit)
+    assert np.array_equal(again.coeffs, want["coeffs"]) and np.array_equal(again.challenges, want["challenges"])

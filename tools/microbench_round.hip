@@ -1,0 +1,183 @@
+// microbench_round.hip -- the GKR sumcheck's two round kernels (csrc/sumcheck_kernels.cuh) alone, compiled from the library's own headers:
+// one translation unit of a few kernels, so that a change to the kernels is measured a minute after it was made (the library's
+// zkmle_sumcheck.hip takes two).  Every timed launch is checked: the folded tables byte for byte and the sums of the partials (mod p)
+// against a plain kernel written here (general field product, one modular operation after the other).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed tools/microbench_round.hip -o tools/microbench_round.bin
+//   tools/microbench_round.bin [log_n = 22] [reps = 100] [grid = 1536] [ntab = 4 | 3 (second product's second factor constant)]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#include "../zk-cryptography-research-implementations_amd/csrc/dev_transcript.cuh"
+using namespace zk;
+using F = Fr381;
+
+// the reference: sumcheck_gkr_protocol.rs:57 (fold every table by r) and :127-140 restricted to the nodes 0, 1, infinity of the NEXT round
+__global__ void ref_fold_round_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *partials) {
+    __shared__ Wide<F> sh[3 * kBlock / 64];
+    Wide<F> acc[3] = {wide_zero<F>(), wide_zero<F>(), wide_zero<F>()};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        for (int p = 0; p < nprod; p++) {
+            Fe<F> lo[2], hi[2];
+            for (int f = 0; f < 2; f++) {
+                const void *src = tabs.in[2 * p + f];
+                if (!src) { lo[f] = hi[f] = const_factor<F>(tabs, p); continue; }
+                const Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q), b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
+                lo[f] = fe_add<F>(a0, fe_mul<F>(r, fe_sub<F>(b0, a0)));
+                hi[f] = fe_add<F>(a1, fe_mul<F>(r, fe_sub<F>(b1, a1)));
+                fe_store<F>(tabs.out[2 * p + f], i, lo[f]);
+                fe_store<F>(tabs.out[2 * p + f], i + q, hi[f]);
+            }
+            wide_add_fe<F>(acc[0], fe_mul<F>(lo[0], lo[1]));
+            wide_add_fe<F>(acc[1], fe_mul<F>(hi[0], hi[1]));
+            wide_add_fe<F>(acc[2], fe_mul<F>(fe_sub<F>(hi[0], lo[0]), fe_sub<F>(hi[1], lo[1])));
+        }
+    }
+    Fe<F> tot;
+    if (block_reduce_wide<F, 3>(acc, sh, tot)) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
+}
+__global__ void ref_round_kernel(SumPolyTables tabs, int nprod, size_t half, void *partials) {
+    __shared__ Wide<F> sh[3 * kBlock / 64];
+    Wide<F> acc[3] = {wide_zero<F>(), wide_zero<F>(), wide_zero<F>()};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        for (int p = 0; p < nprod; p++) {
+            Fe<F> lo[2], hi[2];
+            for (int f = 0; f < 2; f++) {
+                const void *src = tabs.in[2 * p + f];
+                if (!src) { lo[f] = hi[f] = const_factor<F>(tabs, p); continue; }
+                lo[f] = fe_load<F>(src, i);
+                hi[f] = fe_load<F>(src, i + half);
+            }
+            wide_add_fe<F>(acc[0], fe_mul<F>(lo[0], lo[1]));
+            wide_add_fe<F>(acc[1], fe_mul<F>(hi[0], hi[1]));
+            wide_add_fe<F>(acc[2], fe_mul<F>(fe_sub<F>(hi[0], lo[0]), fe_sub<F>(hi[1], lo[1])));
+        }
+    }
+    Fe<F> tot;
+    if (block_reduce_wide<F, 3>(acc, sh, tot)) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
+}
+
+// the memory side of the fused round alone: the same loads and stores, one XOR per word instead of the arithmetic
+__global__ void __launch_bounds__(kBlock) shape_only_kernel(SumPolyTables tabs, int nprod, size_t q, uint32_t *sink) {
+    uint32_t x = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        for (int p = 0; p < nprod; p++) {
+            for (int f = 0; f < 2; f++) {
+                const void *src = tabs.in[2 * p + f];
+                if (!src) continue;
+                const Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q), b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
+                Fe<F> lo, hi;
+                for (int w = 0; w < 8; w++) { lo.l[w] = a0.l[w] ^ b0.l[w]; hi.l[w] = a1.l[w] ^ b1.l[w]; x ^= lo.l[w] + hi.l[w]; }
+                fe_store<F>(tabs.out[2 * p + f], i, lo);
+                fe_store<F>(tabs.out[2 * p + f], i + q, hi);
+            }
+        }
+    }
+    if (x == 0x12345678u) *sink = x;
+}
+
+static Fe<F> host_sum(const std::vector<Fe<F>> &v, size_t first, size_t n) {
+    Fe<F> s = fe_zero<F>();
+    for (size_t i = 0; i < n; i++) s = fe_add<F>(s, v[first + i]);
+    return s;
+}
+
+int main(int argc, char **argv) {
+    const int lg = argc > 1 ? atoi(argv[1]) : 22, reps = argc > 2 ? atoi(argv[2]) : 100;
+    int grid = argc > 3 ? atoi(argv[3]) : 1536;
+    const int ntab = argc > 4 ? atoi(argv[4]) : 4;
+    const size_t n = (size_t)1 << lg, q = n / 4, half = n / 2;
+    if ((size_t)grid * kBlock > q) grid = (int)(q / kBlock > 0 ? q / kBlock : 1);
+    SumPolyTables tabs{}, rtabs{};
+    void *in[4], *out[4], *rout[4], *part, *rpart;
+    for (int k = 0; k < 4; k++) {
+        CK(hipMalloc(&in[k], n * 32)); CK(hipMalloc(&out[k], half * 32)); CK(hipMalloc(&rout[k], half * 32));
+        fill_random_kernel<F><<<4096, kBlock>>>(in[k], n, 0x5EED0900 + k, 0);
+        // edge values where they hurt: the first entries of every stream are p - 1, the next ones 0
+        std::vector<Fe<F>> edge(64);
+        for (int e = 0; e < 64; e++) { for (int w = 0; w < 8; w++) edge[e].l[w] = e < 32 ? F::p(w) : 0u; if (e < 32) edge[e].l[0] -= 1; }
+        for (int s = 0; s < 4; s++) CK(hipMemcpy((char *)in[k] + (size_t)s * q * 32, edge.data() + ((s + k) & 1) * 32, 32 * 32, hipMemcpyHostToDevice));
+    }
+    for (int k = 0; k < 4; k++) {
+        const bool cst = ntab == 3 && k == 3;
+        tabs.in[k] = cst ? nullptr : in[k]; tabs.out[k] = cst ? nullptr : out[k];
+        rtabs.in[k] = cst ? nullptr : in[k]; rtabs.out[k] = cst ? nullptr : rout[k];
+    }
+    const Fe<F> cst = random_element<F>(77, 1), r = random_element<F>(77, 2);
+    for (int w = 0; w < 8; w++) { tabs.cval[1][w] = cst.l[w]; rtabs.cval[1][w] = cst.l[w]; }
+    CK(hipMalloc(&part, (size_t)3 * kMaxReduceBlocks * 32)); CK(hipMalloc(&rpart, (size_t)3 * kMaxReduceBlocks * 32));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time_it = [&](auto &&fn) -> float {
+        for (int i = 0; i < 10; i++) fn();
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < reps; i++) fn();
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        return ms * 1000 / reps;
+    };
+    int bad = 0;
+    {
+        const float us = time_it([&] { shape_only_kernel<<<grid, kBlock>>>(tabs, 2, q, (uint32_t *)part); });
+        const double bytes = (double)ntab * (n + half) * 32;
+        printf("{\"kernel\": \"shape_only (the fused round's loads and stores, no arithmetic)\", \"grid\": %d, \"us\": %.2f, \"GBps\": %.1f}\n", grid, us, bytes / us / 1e3);
+        const int g2 = (int)(q / kBlock);
+        const float us2 = time_it([&] { shape_only_kernel<<<g2, kBlock>>>(tabs, 2, q, (uint32_t *)part); });
+        printf("{\"kernel\": \"shape_only, one pair index per lane\", \"grid\": %d, \"us\": %.2f, \"GBps\": %.1f}\n", g2, us2, bytes / us2 / 1e3);
+    }
+    // ---- fused round ----
+    ref_fold_round_kernel<<<grid, kBlock>>>(rtabs, 2, q, r, rpart);
+    CK(hipDeviceSynchronize());
+    std::vector<Fe<F>> hp((size_t)3 * grid), hr((size_t)3 * grid);
+    uint32_t *rexp_d;                                         // the challenge as the uniform multiplier the exchange would have left (dev_transcript.cuh challenge_expand)
+    { UniMul<F> um; unimul_from<F>(um, r); CK(hipMalloc(&rexp_d, sizeof um)); CK(hipMemcpy(rexp_d, &um, sizeof um, hipMemcpyHostToDevice)); }
+    for (int var = 3; var >= 0; var--) {
+        const int skip1 = var & 1;
+        const uint32_t *rexp = (var & 2) ? rexp_d : nullptr;
+        for (int k = 0; k < 4; k++) CK(hipMemset(out[k], 0xee, half * 32));
+        CK(hipMemset(part, 0, (size_t)3 * grid * 32));
+        const float us = time_it([&] {
+            if (skip1) fold_round_evals_kernel<F, 2, true><<<grid, kBlock>>>(tabs, 2, q, r, part, nullptr, RoundFin{}, rexp, UniArg{});
+            else fold_round_evals_kernel<F, 2, false><<<grid, kBlock>>>(tabs, 2, q, r, part, nullptr, RoundFin{}, rexp, UniArg{});
+        });
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hp.data(), part, hp.size() * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), rpart, hr.size() * 32, hipMemcpyDeviceToHost));
+        int ok = 1;
+        for (int t = 0; t < 3; t++) {
+            if (t == 1 && skip1) continue;
+            if (!fe_eq<F>(host_sum(hp, (size_t)t * grid, grid), host_sum(hr, (size_t)t * grid, grid))) { ok = 0; printf("  evaluation %d differs\n", t); }
+        }
+        std::vector<uint8_t> a(half * 32), b(half * 32);
+        for (int k = 0; k < ntab; k++) {
+            CK(hipMemcpy(a.data(), out[k], half * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), rout[k], half * 32, hipMemcpyDeviceToHost));
+            if (memcmp(a.data(), b.data(), half * 32)) { ok = 0; printf("  folded table %d differs\n", k); }
+        }
+        const double bytes = (double)ntab * (n + half) * 32;
+        printf("{\"kernel\": \"fold_round_evals<2, %s>\", \"multiplier\": \"%s\", \"log_n\": %d, \"ntab\": %d, \"grid\": %d, \"us\": %.2f, \"GBps\": %.1f, \"frac_hbm\": %.3f, \"matches_reference\": %s}\n",
+               skip1 ? "SKIP1" : "all", rexp ? "read" : "worked out per wave", lg, ntab, grid, us, bytes / us / 1e3, bytes / us / 1e3 / 8000, ok ? "true" : "false");
+        bad += !ok;
+    }
+    // ---- first round ----
+    ref_round_kernel<<<grid, kBlock>>>(rtabs, 2, half, rpart);
+    CK(hipDeviceSynchronize());
+    for (int skip1 = 1; skip1 >= 0; skip1--) {
+        CK(hipMemset(part, 0, (size_t)3 * grid * 32));
+        const float us = time_it([&] {
+            if (skip1) round_evals_kernel<F, 2, true><<<grid, kBlock>>>(tabs, 2, half, part, RoundFin{});
+            else round_evals_kernel<F, 2, false><<<grid, kBlock>>>(tabs, 2, half, part, RoundFin{});
+        });
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hp.data(), part, hp.size() * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), rpart, hr.size() * 32, hipMemcpyDeviceToHost));
+        int ok = 1;
+        for (int t = 0; t < 3; t++) {
+            if (t == 1 && skip1) continue;
+            if (!fe_eq<F>(host_sum(hp, (size_t)t * grid, grid), host_sum(hr, (size_t)t * grid, grid))) { ok = 0; printf("  evaluation %d differs\n", t); }
+        }
+        const double bytes = (double)ntab * n * 32;
+        printf("{\"kernel\": \"round_evals<2, %s>\", \"log_n\": %d, \"ntab\": %d, \"grid\": %d, \"us\": %.2f, \"GBps\": %.1f, \"frac_hbm\": %.3f, \"matches_reference\": %s}\n",
+               skip1 ? "SKIP1" : "all", lg, ntab, grid, us, bytes / us / 1e3, bytes / us / 1e3 / 8000, ok ? "true" : "false");
+        bad += !ok;
+    }
+    return bad ? 1 : 0;
+}

@@ -34,6 +34,19 @@ template <class F> int test(const char* name){
     if (it==1){ c=a; dd=b; }                                   // (p-1)(p-1) + (p-1)(p-1): the largest sum
     Fe<F> w2 = fe_add<F>(want, fe_mul_cios<F>(c,dd)), g2 = fe_mul2_u<F>(a,b,c,dd);
     if (!fe_eq<F>(w2,g2)) { if(bad<3) printf("%s mul2 mismatch it=%d\n",name,it); bad++; }
+    // the uniform-multiplier fold (r4): c + b (dd - c) with b as the pass's challenge; it == 1 is (p-1) + (p-1) * 0 with every operand p - 1,
+    // the case whose unreduced value reaches 2 p (the second conditional subtraction of fe_from_u_below_2p)
+    if constexpr (UParams<F>::L == 9) {
+      UniMul<F> um; unimul_from<F>(um, b);
+      Fe<F> wf = fe_add<F>(c, fe_mul_cios<F>(b, fe_sub<F>(dd, c)));
+      Fe<F> gf = fe_from_u_below_2p<F>(ufold<F>(um, u_from_limbs32<F>(c), u_from_limbs32<F>(dd)));
+      if (!fe_eq<F>(wf,gf)) { if(bad<3) printf("%s ufold mismatch it=%d\n",name,it); bad++; }
+      Fe<F> z = fe_zero<F>(), pm = a; if (it==1) {                       // a = p - 1 here
+        Fe<F> w3 = fe_add<F>(pm, fe_mul_cios<F>(b, fe_sub<F>(z, pm)));
+        Fe<F> g3 = fe_from_u_below_2p<F>(ufold<F>(um, u_from_limbs32<F>(pm), u_from_limbs32<F>(z)));
+        if (!fe_eq<F>(w3,g3)) { printf("%s ufold edge mismatch\n",name); bad++; }
+      }
+    }
   }
   printf("%s: %s\n", name, bad? "FAIL":"ok"); return bad;
 }

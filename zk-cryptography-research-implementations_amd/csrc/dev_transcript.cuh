@@ -265,6 +265,20 @@ template <class F> __device__ __forceinline__ Fe<F> mailbox_element(const uint32
 
 constexpr int kMaxPts = kMaxFactors + 1;
 
+// One wave, uniform: the challenge every lane holds, as the uniform multiplier of the fused round that folds by it (ufield.cuh UniMul: row i = r 2^(29 (i + 2))
+// mod p, one product, taken by lane i).  Costs the wave one product's latency once per round; every wave of the next launch then reads 81 words with
+// scalar loads instead of working the rows out itself (sumcheck_kernels.cuh unimul_load).
+template <class F> __device__ __forceinline__ void challenge_expand(uint32_t *exp_out, const Fe<F> &r, unsigned lane) {
+    if constexpr (LazyProducts<F>::value) {
+        if (!exp_out) return;
+        constexpr int L = UParams<F>::L;
+        const Ufe<F> row = unimul_row<F>(r, lane < (unsigned)L ? (int)lane : 0);
+        if (lane < (unsigned)L) {
+#pragma unroll
+            for (int j = 0; j < L; j++) exp_out[lane * L + j] = row.l[j];
+        }
+    }
+}
 // The round's exchange in the producer's last workgroup (sumcheck_kernels.cuh RoundFin): wave 0 of every workgroup, lane t < npts holding
 // the workgroup's sum of evaluation t.
 template <class F> __device__ __forceinline__ void round_finish_in_producer(const RoundFin &f, const Fe<F> &tot) {
@@ -328,6 +342,7 @@ template <class F> __device__ __forceinline__ void round_finish_in_producer(cons
     if (lane == 0) __atomic_store_n(&f.mb->gpu_seq, f.seq, __ATOMIC_RELEASE);
     const Fe<F> r = mailbox_wait_challenge<F>(f.mb, f.seq, lane);
     if (lane == 0) fe_store<F>(f.proof, f.chal_slot, r);
+    challenge_expand<F>(f.exp_out, r, lane);
 }
 
 // what a round's transcript step needs besides the evaluations

@@ -49,6 +49,7 @@ struct RoundFin {
     uint64_t seq;
     void *proof;
     size_t chal_slot;
+    uint32_t *exp_out;       // non-null: the challenge also leaves as a uniform multiplier (ufield.cuh UniMul, L x L words) for the fused round that folds by it
 };
 // wave 0 of every workgroup calls this; lane t < npts holds the workgroup's sum of evaluation t in `tot` (stored form, fully reduced)
 template <class F> __device__ __forceinline__ void round_finish_in_producer(const RoundFin &f, const Fe<F> &tot);   // dev_transcript.cuh
@@ -171,6 +172,47 @@ __device__ __forceinline__ void accumulate_terms_lazy(const Fe<F> (&lo)[2], cons
     // skipped where the skip is free (SKIP1: the variant every large round runs); the three-accumulator variant keeps the loop branch-free
     // (the branch cost it 13 VGPRs and its fourth wave per SIMD).
     if (!SKIP1 || !const2) prod_accumulate<F>(acc[SKIP1 ? 1 : 2], usub<F>(h0, l0), usub<F>(h1, l1));
+}
+// the same on operands that already are normalized 29-bit limbs (the folded pair as ufold leaves it: any representative below 4 p)
+template <class F, bool SKIP1>
+__device__ __forceinline__ void accumulate_terms_lazy_u(const Ufe<F> (&lo)[2], const Ufe<F> (&hi)[2], ProdAcc<F> (&acc)[SKIP1 ? 2 : 3], bool const2) {
+    prod_accumulate<F>(acc[0], lo[0], lo[1]);
+    if constexpr (!SKIP1) prod_accumulate<F>(acc[1], hi[0], hi[1]);
+    if (!SKIP1 || !const2) prod_accumulate<F>(acc[SKIP1 ? 1 : 2], usub<F>(hi[0], lo[0]), usub<F>(hi[1], lo[1]));
+}
+// The pass's challenge as a uniform multiplier (ufield.cuh UniMul) in scalar registers.  `rexp` (81 words, written by whoever produced
+// the challenge: dev_transcript.cuh challenge_expand) is read with uniform loads; without it (and without a kernel argument) lane i < L of every wave works out row i
+// from the challenge itself (one product per wave) and the rows are read back lane by lane.
+// (a launch whose challenge the HOST knows -- zk_sumpoly_fold_round_evals -- carries the rows as a kernel argument)
+struct UniArg {
+    uint32_t valid;
+    uint32_t t[81];
+};
+template <class F> __device__ __forceinline__ void unimul_load(UniMul<F> &m, const uint32_t *__restrict__ rexp, const UniArg &ua, const Fe<F> &r) {
+    constexpr int L = UParams<F>::L;
+    if (rexp) {
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+#pragma unroll
+            for (int j = 0; j < L; j++) m.t[i][j] = __builtin_amdgcn_readfirstlane(rexp[i * L + j]);
+        }
+        return;
+    }
+    if (ua.valid) {
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+#pragma unroll
+            for (int j = 0; j < L; j++) m.t[i][j] = ua.t[(i * L + j) % 81];
+        }
+        return;
+    }
+    const unsigned lane = threadIdx.x & 63u;
+    const Ufe<F> row = unimul_row<F>(r, lane < (unsigned)L ? (int)lane : 0);
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+#pragma unroll
+        for (int j = 0; j < L; j++) m.t[i][j] = __builtin_amdgcn_readlane(row.l[j], i);
+    }
 }
 // 2 L + 1 normalized 29-bit limbs -> 2 N + 2 saturated 32-bit words
 template <class F> struct ProdWide {
@@ -324,7 +366,7 @@ __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs,
 // as the (lo, hi) pair of the NEXT round.
 template <class F, int NFAC, bool SKIP1>
 __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs, int nprod, size_t q, const Fe<F> &r, void *__restrict__ partials,
-                                                      const void *__restrict__ rp, const RoundFin &fin) {
+                                                      const void *__restrict__ rp, const RoundFin &fin, const uint32_t *__restrict__ rexp, const UniArg &ua) {
     constexpr int skip1 = SKIP1 ? 1 : 0;
     if constexpr (NFAC == 2 && LazyProducts<F>::value) {
         __shared__ ProdWide<F> shp[3 * kBlock / 64];
@@ -334,23 +376,28 @@ __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs,
         for (int t = 0; t < NACC; t++) pacc[t] = prod_zero<F>();
         int pending = 0;
         const size_t pstride = (size_t)gridDim.x * blockDim.x;
-        const Multiplier<F> pmr(challenge_arg<F>(r, rp));
+        UniMul<F> um;                                            // the challenge as a uniform multiplier: 99 multiply-adds per fold instead of 162 (ufield.cuh)
+        unimul_load<F>(um, rexp, ua, challenge_arg<F>(r, rp));
+        // The four elements of a table are requested together: left alone the scheduler requests two, folds, requests the other two -- four
+        // loads in flight per wave at three waves per SIMD (r4: 170 -> 166 us on 4 x 2^22).  Requesting the NEXT table ahead as well costs a wave
+        // (196 VGPRs) and loses: 174 us (tools/microbench_round.hip).
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += pstride) {
             for (int p = 0; p < nprod; p++) {
-                Fe<F> lo[2], hi[2];
+                Ufe<F> lo[2], hi[2];
 #pragma unroll
                 for (int f = 0; f < 2; f++) {
                     const void *src = tabs.in[p * 2 + f];
                     void *dst = tabs.out[p * 2 + f];
-                    if (f == 1 && src == nullptr) { lo[1] = hi[1] = const_factor<F>(tabs, p); continue; }
+                    if (f == 1 && src == nullptr) { lo[1] = hi[1] = u_from_limbs32<F>(const_factor<F>(tabs, p)); continue; }
                     Fe<F> a0 = fe_load<F>(src, i), a1 = fe_load<F>(src, i + q);
                     Fe<F> b0 = fe_load<F>(src, i + 2 * q), b1 = fe_load<F>(src, i + 3 * q);
-                    lo[f] = fe_add<F>(a0, pmr.times(fe_sub<F>(b0, a0)));
-                    hi[f] = fe_add<F>(a1, pmr.times(fe_sub<F>(b1, a1)));
-                    fe_store<F>(dst, i, lo[f]);
-                    fe_store<F>(dst, i + q, hi[f]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lo[f] = ufold<F>(um, u_from_limbs32<F>(a0), u_from_limbs32<F>(b0));
+                    hi[f] = ufold<F>(um, u_from_limbs32<F>(a1), u_from_limbs32<F>(b1));
+                    fe_store<F>(dst, i, fe_from_u_below_2p<F>(lo[f]));
+                    fe_store<F>(dst, i + q, fe_from_u_below_2p<F>(hi[f]));
                 }
-                accumulate_terms_lazy<F, SKIP1>(lo, hi, pacc, tabs.in[p * 2 + 1] == nullptr);
+                accumulate_terms_lazy_u<F, SKIP1>(lo, hi, pacc, tabs.in[p * 2 + 1] == nullptr);
                 if (++pending == kProdCarryEvery) {
                     pending = 0;
 #pragma unroll
@@ -389,8 +436,8 @@ __device__ __forceinline__ void fold_round_evals_body(const SumPolyTables &tabs,
 }
 template <class F, int NFAC, bool SKIP1 = false>
 __global__ void __launch_bounds__(kBlock) fold_round_evals_kernel(SumPolyTables tabs, int nprod, size_t q, Fe<F> r, void *__restrict__ partials,
-                                                                  const void *__restrict__ rp, RoundFin fin) {
-    fold_round_evals_body<F, NFAC, SKIP1>(tabs, nprod, q, r, partials, rp, fin);
+                                                                  const void *__restrict__ rp, RoundFin fin, const uint32_t *__restrict__ rexp, UniArg ua) {
+    fold_round_evals_body<F, NFAC, SKIP1>(tabs, nprod, q, r, partials, rp, fin, rexp, ua);
 }
 // The same round for SHORT tables of products of two factors.  Below ~2^15 pair indices the launch above does not fill the
 // device and lasts as long as one lane's chain of products (14 for two products); here a wave takes ONE table for 64 consecutive

@@ -41,6 +41,19 @@ template <> struct UParams<Fr381> {
         constexpr uint32_t t[L] = {0x1ffffffeu, 0x0000000fu, 0x00d20080u, 0x096ff400u, 0x04ff5588u, 0x07f7f65eu, 0x15be6631u, 0x0b3598a0u, 0x001824b1u};
         return t[i];
     }
+    // uniform-multiplier fold (ufold below): 2 p with every limb but the top one raised by 2^29 (borrowed from the next), 2^261 mod p, 2^290 mod p
+    static ZK_HD uint32_t c2p(int i) {
+        constexpr uint32_t t[L] = {0x20000002u, 0x3fffffefu, 0x3f2dff7eu, 0x36900bfeu, 0x3b00aa76u, 0x380809a0u, 0x2a4199cdu, 0x34ca675eu, 0x00e7db4du};
+        return t[i];
+    }
+    static ZK_HD uint32_t k7(int i) {
+        constexpr uint32_t t[L] = {0x1fffffbau, 0x0000022fu, 0x1cb61180u, 0x0a4e5c00u, 0x0ee8b1a2u, 0x16e6aedfu, 0x1907f8bbu, 0x0853ddf7u, 0x004d043fu};
+        return t[i];
+    }
+    static ZK_HD uint32_t k8(int i) {
+        constexpr uint32_t t[L] = {0x0abdac49u, 0x0a129d71u, 0x06a3eff5u, 0x168d894du, 0x15997df8u, 0x09407325u, 0x0b7bc5dcu, 0x1ec6f83eu, 0x0071e0beu};
+        return t[i];
+    }
 };
 
 template <> struct UParams<Fq381> {
@@ -85,6 +98,19 @@ template <> struct UParams<Bn254Fq> {
         constexpr uint32_t t[L] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
         return t[i];
     }
+    // uniform-multiplier fold (ufold below): 2 p with every limb but the top one raised by 2^29 (borrowed from the next), 2^261 mod p, 2^290 mod p
+    static ZK_HD uint32_t c2p(int i) {
+        constexpr uint32_t t[L] = {0x30f9fa8eu, 0x2208c16cu, 0x38e5469du, 0x25aa45a0u, 0x2b0bb2efu, 0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu};
+        return t[i];
+    }
+    static ZK_HD uint32_t k7(int i) {
+        constexpr uint32_t t[L] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+        return t[i];
+    }
+    static ZK_HD uint32_t k8(int i) {
+        constexpr uint32_t t[L] = {0x0dfff5d8u, 0x103ae4bdu, 0x097ea07du, 0x04d7e9a4u, 0x12091fbau, 0x0e81c6b7u, 0x06e1271bu, 0x1f763611u, 0x001af00du};
+        return t[i];
+    }
 };
 
 template <> struct UParams<Bn254Fr> {
@@ -105,6 +131,19 @@ template <> struct UParams<Bn254Fr> {
     }
     static ZK_HD uint32_t r_std(int i) {
         constexpr uint32_t t[L] = {0x0ffffffbu, 0x04b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+        return t[i];
+    }
+    // uniform-multiplier fold (ufold below): 2 p with every limb but the top one raised by 2^29 (borrowed from the next), 2^261 mod p, 2^290 mod p
+    static ZK_HD uint32_t c2p(int i) {
+        constexpr uint32_t t[L] = {0x20000002u, 0x3e1f593eu, 0x3cb848a0u, 0x2fa121e5u, 0x2b0ba505u, 0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu};
+        return t[i];
+    }
+    static ZK_HD uint32_t k7(int i) {
+        constexpr uint32_t t[L] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+        return t[i];
+    }
+    static ZK_HD uint32_t k8(int i) {
+        constexpr uint32_t t[L] = {0x16e2e768u, 0x1cf10ca2u, 0x1ea15493u, 0x19213582u, 0x0e0e45b7u, 0x0e866055u, 0x06e1271bu, 0x1f763611u, 0x001af00du};
         return t[i];
     }
 };
@@ -353,6 +392,70 @@ template <class F> ZK_HD Fe<F> u_to_std(const Ufe<F> &x) {          // x R_u -> 
     return u_to_limbs32<F>(u_reduce_once<F>(umul<F>(x, rs)));
 }
 
+
+// ---- a UNIFORM multiplier: out = a + r (b - a) with r the same for every lane (a round's challenge) ---------------
+// A Montgomery product spends L^2 multiply-adds on the product and L^2 on its reduction.  When the multiplier r is the same for
+// every element of a pass, its shifted multiples  R_i = r 2^(29 (i + 2)) mod p,  i < L,  are L constants of the pass (81 words for the
+// 9-limb fields: scalar registers), and  r D 2^58 = sum_i d_i R_i  (mod p)  for the 29-bit digits d_i of D: L^2 multiply-adds into L
+// columns with no dependency between rows, a value below L 2^31 p -- 34 bits too long -- which TWO Montgomery rows (2 L multiply-adds,
+// a division by 2^58) bring below p (1 + 2^-24).  99 multiply-adds where the scan takes 162 (r4).
+//   D = b - a + 2 p, limb by limb with no carries: the constant is 2 p with every limb but the top raised by 2^29 (c2p), so that every
+//   digit stays positive and below 2^31; a 2^58 rides along in the columns (a_j enters column j + 2), which makes the sum
+//   a + r (b - a) come out of the same two rows.  Inputs: normalized limbs of values below 2^(29 L - 5) (canonical elements here).
+//   Output: normalized limbs of a value congruent to a + r (b - a), below a + p (1 + 2^-24).
+template <class F> struct UniMul {
+    uint32_t t[UParams<F>::L][UParams<F>::L];               // t[i] = r 2^(29 (i + 2)) mod p, canonical, 29-bit limbs
+};
+// row i of the table from the challenge in the stored form (r R_std mod p): (2^(29 (i + 2)) mod p) r R_std / R_std
+template <class F> ZK_HD Ufe<F> unimul_row(const Fe<F> &r_std, int i) {
+    constexpr int L = UParams<F>::L;
+    Ufe<F> k;
+#pragma unroll
+    for (int j = 0; j < L; j++) k.l[j] = i == L - 2 ? UParams<F>::k7(j) : i == L - 1 ? UParams<F>::k8(j) : (j == i + 2 ? 1u : 0u);
+    return u_reduce_once<F>(umul_std<F>(k, r_std));
+}
+template <class F> ZK_HD void unimul_from(UniMul<F> &m, const Fe<F> &r_std) {
+    for (int i = 0; i < UParams<F>::L; i++) {
+        const Ufe<F> row = unimul_row<F>(r_std, i);
+        for (int j = 0; j < UParams<F>::L; j++) m.t[i][j] = row.l[j];
+    }
+}
+template <class F> ZK_HD Ufe<F> ufold(const UniMul<F> &m, const Ufe<F> &a, const Ufe<F> &b) {
+    constexpr int L = UParams<F>::L;
+    uint32_t d[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) d[j] = b.l[j] - a.l[j] + UParams<F>::c2p(j);
+    uint64_t T[L];
+    T[0] = 0;
+    T[1] = 0;
+#pragma unroll
+    for (int j = 2; j < L; j++) T[j] = a.l[j - 2];
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+#pragma unroll
+        for (int j = 0; j < L; j++) T[j] += (uint64_t)d[i] * m.t[i][j];
+    }
+#pragma unroll
+    for (int row = 0; row < 2; row++) {
+        const uint32_t q = ((uint32_t)T[0] * UParams<F>::INV) & UMASK;
+#pragma unroll
+        for (int j = 0; j < L; j++) T[j] += (uint64_t)q * UParams<F>::p(j);
+        const uint64_t carry = T[0] >> UB;
+#pragma unroll
+        for (int j = 0; j + 1 < L; j++) T[j] = T[j + 1];
+        T[L - 1] = a.l[L - 2 + row];
+        T[0] += carry;
+    }
+    return u_normalize_columns<F>(T);
+}
+// normalized limbs of a value below 2 p (1 + 2^-24) (what ufold leaves for canonical inputs) -> the canonical element, 32-bit limbs.
+// The second subtraction is taken by one lane in 2^31 or so (value >= 2 p: both a and the product within 2^-24 p of p).
+template <class F> ZK_HD Fe<F> fe_from_u_below_2p(const Ufe<F> &x) {
+    Fe<F> s = u_to_limbs32<F>(x);
+    fe_cond_sub_p<F>(s, 0);
+    if (s.l[F::N - 1] >= F::p(F::N - 1)) fe_cond_sub_p<F>(s, 0);
+    return s;
+}
 
 // ---- the library's field product --------------------------------------------------------------------------------
 // device: unsaturated scan (1.45x the saturated CIOS as hipcc compiles it, 1.9x without the conversions);

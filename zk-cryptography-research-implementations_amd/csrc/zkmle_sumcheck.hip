@@ -180,11 +180,15 @@ template <class F> struct DeviceRounds {
     void *proof() const { return base() + kHead + nbasis * 4 * F::N; }
     void *slot_ptr(size_t s) const { return (char *)proof() + s * 4 * F::N; }
     size_t bytes() const { return kHead + (nbasis + nslots) * 4 * F::N; }
+    // behind the slots: the current challenge as a uniform multiplier (ufield.cuh UniMul), written by the exchange that receives it and read by
+    // the fused round that folds by it.  One area per proof: a fused round has read it before its last workgroup writes the next one.
+    static constexpr size_t kExpBytes = 512;
+    uint32_t *uexp() const { return (uint32_t *)(base() + ((bytes() + 15) & ~(size_t)15)); }
     int init(Transcript &tr, const std::vector<Fe<F>> &basis_flat, size_t slots, bool allow_host = true) {
         static_assert(sizeof(DevSponge) <= kHead, "sponge header");
         nbasis = basis_flat.size();
         nslots = slots;
-        ZK_TRY(buf.alloc(bytes()));
+        ZK_TRY(buf.alloc(((bytes() + 15) & ~(size_t)15) + kExpBytes));
         ZK_TRY(sync_words(&syncw));
         host_mode = allow_host && host_transcript_default() && g_host_rounds_active == 0;
         void *h = nullptr, *d = nullptr;
@@ -418,20 +422,21 @@ template <class F> struct DeviceRounds {
     // host mode: the round's exchange runs in the last workgroup of the kernel that produces its evaluations (sumcheck_kernels.cuh RoundFin,
     // dev_transcript.cuh round_finish_in_producer) instead of in a finish kernel: registers the request, hands back what that launch needs.
     // `grid` = the producer's workgroups.
-    int round_fin(int grid, int npts, int mode, int with_claim, size_t claim_slot, size_t msg_slot, size_t chal_slot, int derive_prev, RoundFin *out) {
+    int round_fin(int grid, int npts, int mode, int with_claim, size_t claim_slot, size_t msg_slot, size_t chal_slot, int derive_prev, RoundFin *out,
+                  bool expand = false) {
         if (!host_mode) return ZK_E_ARG;
         push_req(Req{kRound, mode, npts, with_claim, derive_prev, 0, claim_slot, msg_slot, chal_slot, 0, {0, 0, 0, 0, 0, 0, 0}});
         unsigned group = 32;
         while ((unsigned)(grid + group - 1) / group > 200u) group *= 2;   // one 64-byte counter slot per group (context.h kSyncCounterBytes)
         *out = RoundFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), npts, derive_prev, group, nullptr, mb_dev, (uint64_t)nreq(), proof(),
-                        chal_slot};
+                        chal_slot, expand ? uexp() : nullptr};
         return ZK_OK;
     }
     // the same for a sharded table: the kernel's last workgroup leaves the npts sums as limb words for the all-reduce, nothing is posted
     RoundFin round_fin_limbs(int grid, int npts, int skip1, uint64_t *limbs_out) const {
         unsigned group = 32;
         while ((unsigned)(grid + group - 1) / group > 200u) group *= 2;
-        return RoundFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), npts, skip1, group, limbs_out, nullptr, 0, nullptr, 0};
+        return RoundFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), npts, skip1, group, limbs_out, nullptr, 0, nullptr, 0, nullptr};
     }
     // host mode, basic sumcheck (basic_multi.cuh): rounds round .. round + m - 1 from the 2^m segment sums an all-reduce has left as limb
     // words (sharded table); slots of round k: 1 + 3 k, 2 + 3 k (sums), 3 + 3 k (challenge), claim 0
@@ -795,7 +800,8 @@ inline bool fold_round_takes_split(int nprod, int nfac, size_t q, bool may_split
 // `grid` = the number of partials written per evaluation point.  With `may_split` the caller lets short rounds of two-factor
 // products take the split kernel, which changes `grid` (sumcheck_kernels.cuh).
 template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int nprod, int nfac, size_t q, const Fe<F> &r, void *part, int &grid,
-                                               const void *rp = nullptr, int skip1 = 0, bool may_split = false, const RoundFin *fin = nullptr) {
+                                               const void *rp = nullptr, int skip1 = 0, bool may_split = false, const RoundFin *fin = nullptr,
+                                               const uint32_t *rexp = nullptr) {
     const RoundFin f = fin ? *fin : RoundFin{};
     if (fold_round_takes_split(nprod, nfac, q, may_split)) {
         grid = (int)(q / 64);
@@ -803,13 +809,23 @@ template <class F> int launch_fold_round_evals(const SumPolyTables &tabs, int np
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
+    UniArg ua{};                                                      // a challenge the host knows travels as the uniform multiplier's rows (ufield.cuh UniMul)
+    if constexpr (LazyProducts<F>::value) {
+        if (nfac == 2 && !rp && !rexp) {
+            UniMul<F> um;
+            unimul_from<F>(um, r);
+            static_assert(sizeof um.t == sizeof ua.t, "nine rows of nine limbs");
+            memcpy(ua.t, um.t, sizeof ua.t);
+            ua.valid = 1;
+        }
+    }
     if (skip1) {
-        if (nfac == 1) fold_round_evals_kernel<F, 1, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
-        else if (nfac == 2) fold_round_evals_kernel<F, 2, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
-        else fold_round_evals_kernel<F, 3, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
-    } else if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
-    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
-    else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f);
+        if (nfac == 1) fold_round_evals_kernel<F, 1, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f, rexp, ua);
+        else if (nfac == 2) fold_round_evals_kernel<F, 2, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f, rexp, ua);
+        else fold_round_evals_kernel<F, 3, true><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f, rexp, ua);
+    } else if (nfac == 1) fold_round_evals_kernel<F, 1><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f, rexp, ua);
+    else if (nfac == 2) fold_round_evals_kernel<F, 2><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f, rexp, ua);
+    else fold_round_evals_kernel<F, 3><<<grid, kBlock, 0, cur_stream()>>>(tabs, nprod, q, r, part, rp, f, rexp, ua);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -901,6 +917,12 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
             else memcpy(tabs.cval[k / nfac], const_host + (k / nfac) * L64, esz);
         }
     }
+    // The fused round of the two-factor lazy kernel folds by the challenge as a UNIFORM multiplier (ufield.cuh UniMul); the exchange that receives
+    // the challenge of a round whose fold is such a launch leaves it in that form (host-assisted step; otherwise the kernel's waves work it out).
+    const size_t tail_from0 = (nfac == 2 && nprod >= 2) ? kTailLen / 2 : kTailLen;
+    auto takes_uniform = [&](size_t cl_folded) {                     // cl_folded: the length of the tables that challenge folds
+        return dr.host_mode && nfac == 2 && LazyProducts<F>::value && cl_folded > tail_from0 && !fold_round_takes_split((int)nprod, (int)nfac, cl_folded / 4, true);
+    };
     {   // round 0 evaluations
         size_t half = len / 2;
         int grid = reduce_grid_for(half);
@@ -908,7 +930,7 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
         const int skip0 = (own_claim && dr.host_mode && nfac == 2 && LazyProducts<F>::value && half >= ((size_t)1 << 14)) ? 1 : 0;
         if (dr.host_mode) {                                            // the exchange runs in the kernel's last workgroup
             RoundFin fin;
-            ZK_TRY(dr.round_fin(grid, (int)npts, 1, with_claim, claim_slot, s0, s0 + npts, skip0, &fin));
+            ZK_TRY(dr.round_fin(grid, (int)npts, 1, with_claim, claim_slot, s0, s0 + npts, skip0, &fin, takes_uniform(len)));
             ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid, skip0, &fin)));
         } else {
             ZK_TRY((launch_round_evals<F>(tabs, (int)nprod, (int)nfac, half, part, grid, skip0)));
@@ -933,8 +955,9 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
         if (dr.host_mode) {
             RoundFin fin;
             const int g = fold_round_takes_split((int)nprod, (int)nfac, q, true) ? (int)(q / 64) : grid;
-            ZK_TRY(dr.round_fin(g, (int)npts, 1, 0, 0, s0 + per * (round + 1), s0 + per * (round + 1) + npts, skip1, &fin));
-            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true, &fin)));
+            ZK_TRY(dr.round_fin(g, (int)npts, 1, 0, 0, s0 + per * (round + 1), s0 + per * (round + 1) + npts, skip1, &fin, takes_uniform(ol)));
+            ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true, &fin,
+                                               takes_uniform(cl) ? dr.uexp() : nullptr)));
         } else {
             ZK_TRY((launch_fold_round_evals<F>(tabs, (int)nprod, (int)nfac, q, fe_zero<F>(), part, grid, rp, skip1, true)));
             ZK_TRY(dr.launch_finish(part, (size_t)grid, (int)npts, 1, 0, 0, s0 + per * (round + 1), s0 + per * (round + 1) + npts, skip1, per));
