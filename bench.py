@@ -275,8 +275,8 @@ def fold_leg(env, zk, n, seed, first, stride, r, steps, warmup, prewarm_s=0.4):
     def step():
         _lib.check(L.zk_mle_fold(table._h, 0, _lib.p64(r), out._h, stream))
 
-    # clock pre-warm (untimed, outside the W / K protocol): a cold MI355X needs a few hundred milliseconds of
-    # load before it holds its sustained clock; without this a short K reads 20 % low
+    # clock pre-warm (untimed, outside the W / K protocol, reported in the line as `prewarm_s`): a cold MI355X needs a few hundred
+    # milliseconds of load before it holds its sustained clock; without this a short K reads 20 % low
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < prewarm_s:
         for _ in range(50):
@@ -304,7 +304,8 @@ def fold_leg(env, zk, n, seed, first, stride, r, steps, warmup, prewarm_s=0.4):
     for i in range(len(marks) - 1):
         cnt = min(chunk, steps - i * chunk)
         per_chunk.append(marks[i].elapsed_time(marks[i + 1]) / cnt)
-    return {"dt": dt, "kernel_ms": kern_ms, "kernel_ms_median": statistics.median(per_chunk), "chunks": len(per_chunk)}, table, out
+    return {"dt": dt, "kernel_ms": kern_ms, "kernel_ms_median": statistics.median(per_chunk), "chunks": len(per_chunk),
+            "prewarm_s": prewarm_s}, table, out
 
 
 def run_rank(env, args, zk):
@@ -337,7 +338,7 @@ def run_rank(env, args, zk):
         per = f"a 2^{args.log_n}-entry table per GPU"
     result = {
         "metric": f"field-mul/s (2^{args.log_n} MLE fold)", "value": muls / dt, "unit": "field-mul/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "steps": args.steps, "warmup": args.warmup, "prewarm_s": t["prewarm_s"], "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": f"{args.log_n}-variable MLE fold (partial_evaluate var 0), BLS12-381 Fr, {per}",
@@ -400,6 +401,7 @@ def run_rank(env, args, zk):
             failed.append("msm")
     if world == 1 and not args.no_configs:
         result["configs"] = baseline_configs(zk, args)
+        result["paths"] = other_paths(zk, args)
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(zk, field)
     if failed:
@@ -641,6 +643,11 @@ def msm_leg(zk, env, args, shared=None):
 # 6 products (392) + 2 squarings (301) + 1 dual product with one reduction (588).  Source-level count = the ISA's common path
 # (tools/count_mads.py, profiles/r2/msm_mad_count.txt).
 MADS_PER_MIXED_ADD = 6 * 392 + 2 * 301 + 588
+# v_mad_u64_u32 per pair index of the GKR round kernels on 2 products x 2 factors (ISA counts of the loop bodies, tools/kernel_isa_stats.py;
+# source level: a fold by the uniform multiplier = 81 + 2 x 9, a raw product = 81; Fr381's p has a limb equal to 1, which saves a few):
+# fused round = 8 folds + 4 raw products, first round = 6 raw products
+MADS_FOLD_ROUND = 1100
+MADS_ROUND = 486
 
 
 def msm_roofline(st):
@@ -712,6 +719,8 @@ def baseline_configs(zk, args):
     MP = zk.MultilinearPolynomial
     stream = torch.cuda.current_stream().cuda_stream
     out = {}
+    if not args.no_cpu_baseline:
+        out["cfg1"] = config1(zk)
     # -- config 2: 20-variable sumcheck fold + the whole Prover::prove (prover.rs:35-71)
     n = 1 << 20
     poly = MP.random(0, n, 0x5EED0002)
@@ -739,6 +748,8 @@ def baseline_configs(zk, args):
     out["cfg2"] = {"what": "20-variable MLE sumcheck fold, BLS12-381 Fr, 1xMI355X", "fold_us": fold_ms * 1e3, "fold_field_mul_per_s": (n // 2) / (fold_ms * 1e-3),
                    "fold_GBps": gb, "fold_frac": gb / HBM_PEAK_GBPS, "fold_note": "the 2^20 table (32 MiB in + 16 MiB out) fits the 256 MiB MALL: above-HBM rates are cache hits",
                    "prove_ms": prove_s * 1e3, "rounds_ms": st["ms_rounds"], "absorb_ms": st["ms_absorb"],
+                   "absorb_GBps": 32.0 * n / (st["ms_absorb"] * 1e-3) / 1e9,
+                   "absorb_note": "prove_ms is the reference's protocol, not a GPU number: prover.rs:38-39 absorbs the whole table into ONE sequential Keccak sponge (one host core; the GPU converts to canonical big-endian bytes beside it)",
                    "rounds_field_mul_per_s": (n - 1) / (st["ms_rounds"] * 1e-3), "post_check": {"verifier_accepts": bool(verified)}}
     del poly, dst, prover, proof
     # -- config 3: multilinear_kzg::commit, 2^20-scalar Pippenger MSM (multilinear_kzg.rs:25-45)
@@ -820,19 +831,162 @@ def baseline_configs(zk, args):
     q = ng // 4
     fre_bytes = 4 * (ng + ng // 2) * 32.0
     re_bytes = 4 * ng * 32.0
+    mad_peak, mad_src = measured_mad_peak()
+    absorb_s = prove_s - sum(float(v) for v in proof.ms_layers) * 1e-3
     out["cfg4"] = {"what": "GKR prover, depth-3 layered circuit, 2^22 gates/layer (random wiring), BLS12-381 Fr, 1xMI355X; sparse (linear-time) prover",
                    "circuit_compile_s": compile_s, "prove_s": prove_s, "device_ms_per_layer": [float(v) for v in proof.ms_layers], "verify_s": verify_s,
                    "gates_per_s": depth * ng / prove_s,
+                   "absorb_s": absorb_s, "absorb_GBps": 32.0 * ng / absorb_s / 1e9,
+                   "absorb_note": "prove_s minus the layers' device time: the sequential host Keccak absorb of the 2^22-entry output layer (gkr_protocol.rs:49) -- the reference's protocol, one host core, not a GPU number",
                    "round_kernels": {
                        "what": "4 tables of 2^22 entries (2 products x 2 factors), HIP events over 200 back-to-back enqueue-only launches",
                        "fold_round_evals_kernel": {"us": fre_ms * 1e3, "GBps": fre_bytes / (fre_ms * 1e-3) / 1e9, "frac": fre_bytes / (fre_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                                    "algorithmic_bytes": fre_bytes, "field_mul_per_s": 12.0 * q / (fre_ms * 1e-3),
-                                                   "field_mul_per_pair_index": "8 fold products + 4 evaluation products (nodes 0 and infinity; the node 1 is derived)"},
+                                                   "field_mul_per_pair_index": "8 fold products + 4 evaluation products (nodes 0 and infinity; the node 1 is derived)",
+                                                   "mads_per_pair_index": MADS_FOLD_ROUND, "Tmad_per_s": MADS_FOLD_ROUND * q / (fre_ms * 1e-3) / 1e12,
+                                                   "frac_valu": MADS_FOLD_ROUND * q / (fre_ms * 1e-3) / mad_peak},
                        "round_evals_kernel": {"us": re_ms * 1e3, "GBps": re_bytes / (re_ms * 1e-3) / 1e9, "frac": re_bytes / (re_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                               "algorithmic_bytes": re_bytes, "field_mul_per_s": 6.0 * (ng // 2) / (re_ms * 1e-3),
-                                              "field_mul_per_pair_index": "6 evaluation products (nodes 0, 1, infinity of 2 products)"}},
+                                              "field_mul_per_pair_index": "6 evaluation products (nodes 0, 1, infinity of 2 products)",
+                                              "mads_per_pair_index": MADS_ROUND, "Tmad_per_s": MADS_ROUND * (ng // 2) / (re_ms * 1e-3) / 1e12,
+                                              "frac_valu": MADS_ROUND * (ng // 2) / (re_ms * 1e-3) / mad_peak},
+                       "frac_valu_note": "v_mad_u64_u32 per pair index (ISA count, tools/kernel_isa_stats.py: profiles/r4/gkr_round_kernels_isa.md) x pair indices / time, against the "
+                                         "in-run multiply-add peak (" + mad_src + "); multiply-adds are ~40 % of these kernels' VALU instructions, so frac_valu understates how busy the VALU pipe is"},
                    "post_check": {"sparse_verifier_accepts": bool(ok)},
                    "note": "prove_s includes the sequential host Keccak absorb of the 2^22-entry output layer; circuit_compile_s is paid once per circuit"}
+    return out
+
+
+def config1(zk):
+    """BASELINE config 1: the reference's own bench shape (sumcheck_protocol/benches/basic_sumcheck_benchmark.rs: one iteration = Prover::init +
+    prove AND Verifier::verify) on a 12-variable BLS12-381 Fr table, the oracle on ONE host thread; the product's proof of the same table
+    beside it (it must be the same bytes)."""
+    import numpy as np
+    from oracle import oracle as O
+    from zkmle_amd import _lib
+    n = 1 << 12
+    tab = np.zeros((n, 4), np.uint64)
+    _lib.check(zk.lib().zk_host_fill_random(0, SEED_TABLE, 0, n, _lib.p64(tab)))
+    cs, rp, _ = O.sumcheck_basic_prove(0, tab)
+    O.sumcheck_basic_verify(0, tab, cs, rp)
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:                   # ~2 s of single-core work
+        cs, rp, _ = O.sumcheck_basic_prove(0, tab)
+        okr = O.sumcheck_basic_verify(0, tab, cs, rp)
+        reps += 1
+    cpu_ms = (time.perf_counter() - t0) / reps * 1e3
+    zk.Verifier.init().verify(zk.Prover.init(0, tab).prove())
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        proof = zk.Prover.init(0, tab).prove()
+        ok = zk.Verifier.init().verify(proof)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    same = bool(np.array_equal(proof.initial_claimed_sum, cs) and np.array_equal(proof.round_univariate_polynomials, rp))
+    if not (ok and okr and same):
+        raise SystemExit("bench.py: config 1: the GPU proof of the 2^12 table differs from the oracle's or is rejected")
+    return {"what": "sumcheck_protocol bench shape (init + prove + verify) on a 12-variable BLS12-381 Fr table", "cpu_reference_ms": cpu_ms,
+            "cpu": {"kind": "port", "cores": 1, "iterations": reps, "sample": "the oracle's restatement of prover.rs / verifier.rs, one host thread"},
+            "gpu_ms": sorted(ts)[len(ts) // 2], "gpu_note": "host upload of the 128 KiB table + proof + verifier's evaluate per iteration: latency-bound (12 rounds), the table is too small to occupy the chip",
+            "post_check": {"gpu_proof_equals_oracle_proof": same, "verifier_accepts": bool(ok)}}
+
+
+def other_paths(zk, args):
+    """The other functions `north_star` names, at BASELINE's largest size on this GPU, each timed and then checked: evaluate (evaluation_form.rs:21-33),
+    trusted setup (trusted_setup.rs:24-60), commit + open_and_prove (multilinear_kzg.rs:25-126; the opening that was timed goes through the pairing
+    check :131-158), dense gkr::prove on the largest reference-shaped circuit whose dense wiring tables are kept (gkr_protocol.rs:26-143)."""
+    import random
+    import numpy as np
+    import torch
+    from zkmle_amd import _lib
+    L = zk.lib()
+    MP = zk.MultilinearPolynomial
+    out = {}
+
+    def sync():
+        torch.cuda.synchronize()
+
+    lg = args.log_n
+    n = 1 << lg
+    # -- evaluate: n - 1 field multiplications, 96 (n - 1) algorithmic bytes (SURVEY 8d)
+    poly = MP.random(0, n, 0x5EED0002)
+    point = MP.random(0, lg, 77).evaluated_values
+    for _ in range(3):
+        poly.evaluate(point)
+    ts = []
+    for _ in range(20):
+        sync(); t0 = time.perf_counter()
+        v = poly.evaluate(point)
+        ts.append(time.perf_counter() - t0)
+    ev_s = sorted(ts)[len(ts) // 2]
+    cur = poly                                              # the check: the same value as `lg` successive partial_evaluate launches (the fold kernel)
+    for i in range(lg):
+        cur = MP.partial_evaluate(cur, 0, point[i])
+    chain_ok = bool(np.array_equal(np.asarray(v).reshape(-1), cur.evaluated_values.reshape(-1)))
+    if not chain_ok:
+        raise SystemExit("bench.py: evaluate() differs from the chain of partial_evaluate launches")
+    floor = 96.0 * (n - 1)
+    out[f"evaluate_2p{lg}"] = {"what": f"MultilinearPolynomial::evaluate on a 2^{lg}-entry Fr table, one call (host wall time, value downloaded)", "ms": ev_s * 1e3,
+                               "field_mul_per_s": (n - 1) / ev_s, "floor_bytes": floor, "GBps_vs_floor": floor / ev_s / 1e9, "frac_vs_floor": floor / ev_s / 1e9 / HBM_PEAK_GBPS,
+                               "note": "the floor is the reference's schedule (one pass per variable: 96 B per multiplication); the product folds up to 4 variables per pass, "
+                                       "so it moves fewer bytes than the floor counts and can exceed 1.0 of it",
+                               "post_check": {"equals_chain_of_partial_evaluate": chain_ok}}
+    del cur
+    # -- trusted setup, commit, open_and_prove, verify
+    taus = zk.from_ints(0, [0x1000003 * (i + 1) + 12345 for i in range(lg)])
+    opening = zk.from_ints(0, [0x2000003 * (i + 7) + 999 for i in range(lg)])
+    sync(); t0 = time.perf_counter()
+    setup = zk.TrustedSetup.initialize_setup(taus)
+    sync(); setup_s = time.perf_counter() - t0
+    out[f"setup_2p{lg}"] = {"what": f"TrustedSetup::initialize_setup for {lg} variables: compute_lagrange_basis + 2^{lg} fixed-base [L_i(tau)]G + batch to affine + {lg} G2 powers (host)",
+                            "s": setup_s, "points_per_s": n / setup_s}
+    zk.MultilinearKZG.commit_to_polynomial(poly, setup)
+    sync(); t0 = time.perf_counter()
+    com = zk.MultilinearKZG.commit_to_polynomial(poly, setup)
+    sync(); commit_s = time.perf_counter() - t0
+    sync(); t0 = time.perf_counter()
+    setup.opening_key()
+    sync(); key_s = time.perf_counter() - t0
+    zk.MultilinearKZG.open_and_prove(poly, setup, opening)
+    opens = []
+    for _ in range(3):
+        sync(); t0 = time.perf_counter()
+        prf = zk.MultilinearKZG.open_and_prove(poly, setup, opening)
+        sync(); opens.append(time.perf_counter() - t0)
+    open_s = min(opens)
+    t0 = time.perf_counter()
+    verified = bool(zk.MultilinearKZG.verify(setup, com, opening, prf))
+    verify_s = time.perf_counter() - t0
+    same_eval = bool(np.array_equal(np.asarray(prf.evaluation).reshape(-1), np.asarray(poly.evaluate(opening)).reshape(-1)))
+    if not (verified and same_eval):
+        raise SystemExit("bench.py: the KZG opening that was timed fails the pairing check")
+    out[f"kzg_commit_2p{lg}"] = {"what": "commit_to_polynomial on a real setup ([L_i(tau)]G bases)", "ms": commit_s * 1e3, "terms_per_s": n / commit_s}
+    out[f"kzg_open_2p{lg}"] = {"what": f"open_and_prove: evaluate + {lg} quotient MSMs of 2^{lg - 1} .. 1 terms on pre-summed bases (opening key built once per setup: {key_s * 1e3:.1f} ms)",
+                               "ms": open_s * 1e3, "terms_per_s": (n - 1) / open_s, "opening_key_ms": key_s * 1e3,
+                               "post_check": {"pairing_check_of_the_timed_opening": verified, "verify_s": verify_s, "pairings": lg + 1, "evaluation_equals_evaluate": same_eval}}
+    del setup, prf, poly
+    # -- dense gkr::prove, the reference's own shape (layer i: 2^i gates reading 2^(i+1) wires; dense add_i / mul_i of 2^(3i+2) entries)
+    depth = 8
+    rng = random.Random(8)
+    layers = []
+    for i in range(depth):
+        n_in = 1 << (i + 1)
+        layers.append(zk.gkr.Layer([zk.gkr.Gate(rng.randrange(n_in), rng.randrange(n_in), o, rng.choice([0, 1])) for o in range(1 << i)]))
+    circuit = zk.gkr.Circuit(0, layers)
+    x = MP.random(0, 1 << depth, 0x5EED0008).evaluated_values
+    zk.gkr.prove(circuit, x)
+    ts = []
+    for _ in range(3):
+        sync(); t0 = time.perf_counter()
+        gp = zk.gkr.prove(circuit, x)
+        sync(); ts.append(time.perf_counter() - t0)
+    ok = zk.gkr.verify(circuit, gp, x)
+    if not ok:
+        raise SystemExit("bench.py: the dense GKR proof that was timed is rejected by gkr_protocol::verify")
+    out["gkr_dense"] = {"what": f"gkr_protocol::prove, reference-shaped circuit of depth {depth} (2^{depth} inputs; the last layer's dense add_i / mul_i have 2^{3 * (depth - 1) + 2} entries each, "
+                                f"its f(b,c) tables 2^{2 * (depth - 1) + 2}), BLS12-381 Fr", "ms": min(ts) * 1e3, "rounds": sum(2 * (i + 1) for i in range(depth)),
+                        "post_check": {"verifier_accepts": bool(ok)},
+                        "note": "the dense wiring tables are the reference's representation (exponential in the layer index); circuits of BASELINE config 4's size go through the gate-list prover (configs.cfg4)"}
     return out
 
 

@@ -42,7 +42,7 @@ def test_one_gpu_line_has_the_contract_keys():
     p = run(["--steps", "5", "--warmup", "2", "--log-n", "16", "--msm-reps", "1", "--no-configs"])
     assert p.returncode == 0, p.stderr[-2000:]
     d = last_json(p.stdout)
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "prewarm_s", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline", "collectives", "post_check"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -57,6 +57,24 @@ def test_one_gpu_line_has_the_contract_keys():
     c5 = d["config5_strong"]
     assert c5["sumcheck"]["verifier_equations_hold"] is True and c5["msm"]["same_point_on_every_rank"] is True
     assert c5["msm"]["post_check"]["holds"] is True
+
+
+@pytest.mark.gpu
+def test_one_gpu_line_times_every_named_path_and_config():
+    # the functions north_star names beyond the fold and the MSM (evaluate, setup, commit, open_and_prove, dense gkr::prove) and BASELINE configs 1-4,
+    # each timed AND checked; sizes follow --log-n where they are not fixed by BASELINE
+    p = run(["--steps", "5", "--warmup", "2", "--log-n", "16", "--msm-reps", "1", "--no-msm", "--no-config5"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = last_json(p.stdout)
+    pa, cf = d["paths"], d["configs"]
+    assert pa["evaluate_2p16"]["post_check"]["equals_chain_of_partial_evaluate"] is True and pa["evaluate_2p16"]["ms"] > 0
+    assert pa["kzg_open_2p16"]["post_check"]["pairing_check_of_the_timed_opening"] is True and pa["kzg_open_2p16"]["post_check"]["pairings"] == 17
+    assert pa["setup_2p16"]["s"] > 0 and pa["kzg_commit_2p16"]["terms_per_s"] > 0
+    assert pa["gkr_dense"]["post_check"]["verifier_accepts"] is True
+    assert cf["cfg1"]["post_check"]["gpu_proof_equals_oracle_proof"] is True and cf["cfg1"]["cpu"]["cores"] == 1
+    assert cf["cfg2"]["absorb_GBps"] > 0 and cf["cfg4"]["absorb_GBps"] > 0
+    rk = cf["cfg4"]["round_kernels"]
+    assert 0 < rk["fold_round_evals_kernel"]["frac_valu"] < 1 and 0 < rk["round_evals_kernel"]["frac_valu"] < 1
 
 
 @pytest.mark.gpu
