@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--msm-reps", type=int, default=3)
     ap.add_argument("--require-rccl", action="store_true",
                     help="exit non-zero unless the collectives ran over RCCL and every config-5 leg succeeded")
+    ap.add_argument("--preflight", action="store_true",
+                    help="N > 1: build the communicators, run every collective the provers use once on known data and one small sharded proof / MSM "
+                         "of each kind against the checker, print one JSON line and exit (non-zero on any mismatch): seconds, before a long run")
     ap.add_argument("--rehearse", action="store_true",
                     help="debug: the N > 1 code path with every rank a thread of this process on cuda:0 (one-GPU boxes)")
     return ap.parse_args()
@@ -196,6 +199,14 @@ def main():
         if args.require_rccl and collectives["library"] != "rccl":
             raise SystemExit("bench.py --require-rccl: the provers' communicator is not RCCL")
     env = RankEnv(rank, world, comm, collectives, dist=dist)
+    if args.preflight:
+        line = preflight(env, zk)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        comm.close()
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(0 if line["ok"] else 4)
     result = run_rank(env, args, zk)
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -231,7 +242,8 @@ def rehearse_threads(args, zk):
             _lib.check(lib.zk_set_stream(C.c_void_p(st.cuda_stream)))
             comm = group.comm(rank)
             coll = dict(collectives, library=comm.native_backend())
-            results[rank] = run_rank(RankEnv(rank, world, comm, coll, tgroup=tgroup), args, zk)
+            renv = RankEnv(rank, world, comm, coll, tgroup=tgroup)
+            results[rank] = preflight(renv, zk) if args.preflight else run_rank(renv, args, zk)
         except BaseException as e:                        # noqa: BLE001
             import traceback
             errors.append((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
@@ -257,6 +269,89 @@ def rehearse_threads(args, zk):
             print(f"rank {rank} failed:\n{tb}", file=sys.stderr)
         raise SystemExit(1)
     print(json.dumps(results[0]), flush=True)
+    if args.preflight and not results[0]["ok"]:
+        raise SystemExit(4)
+
+
+# ---- N > 1 preflight ----------------------------------------------------------------------------------------------------------------
+def preflight(env, zk):
+    """Everything a multi-rank run depends on, in seconds: the provers' communicator (RCCL, or what stands in for it) carries each collective
+    the provers use -- the int64 limb all-reduce (exactness past 2^32), the all-gather (rank order), the broadcast of the 208-byte sponge
+    (from the first and from the last rank) -- on known data; then one small proof / MSM of each sharded kind against the checker: the
+    basic sumcheck WITH the whole-table absorb on a table of four absorb chunks (the chunked gather's order), the GKR sumcheck, evaluate and the
+    MSM.  -> {"ok": bool, "checks": {...}} on every rank (the verdict is agreed: one more exchange at the end)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    from zkmle_amd import _lib
+    S = zk.sharded
+    lib = S._declare_host()
+    rank, world, comm = env.rank, env.world, env.comm
+    h = comm.native()
+    t0 = time.perf_counter()
+    checks = {}
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def dptr(t):
+        return C.c_void_p(t.data_ptr())
+
+    # 1. all-reduce(SUM, int64) of limb words: every rank contributes 2^32 - 1 - i, so the sums pass 2^32 (27 words = one GKR round; 2^7 x 9 = the largest pass)
+    for count in (27, 9 << 7):
+        v = torch.tensor([0xFFFFFFFF - i for i in range(count)], dtype=torch.int64, device=dev)
+        _lib.check(lib.zk_comm_all_reduce_sum_i64(h, dptr(v), count))
+        torch.cuda.synchronize()
+        want = np.array([world * (0xFFFFFFFF - i) for i in range(count)], np.int64)
+        checks[f"all_reduce_i64_{count}_words_exact"] = bool(np.array_equal(v.cpu().numpy(), want))
+    # 2. all-gather: 96 bytes per rank (an affine point), slot r must hold rank r's bytes
+    send = torch.full((96,), rank + 1, dtype=torch.uint8, device=dev)
+    recv = torch.zeros((world * 96,), dtype=torch.uint8, device=dev)
+    _lib.check(lib.zk_comm_all_gather(h, dptr(send), dptr(recv), 96))
+    torch.cuda.synchronize()
+    got = recv.cpu().numpy().reshape(world, 96)
+    checks["all_gather_rank_order"] = bool(all((got[r] == r + 1).all() for r in range(world)))
+    # 3. broadcast of 208 bytes (25 sponge lanes + fill) from the first and from the last rank
+    for root in sorted({0, world - 1}):
+        b = torch.tensor([(7 * i + root) % 251 if rank == root else 0 for i in range(208)], dtype=torch.uint8, device=dev)
+        _lib.check(lib.zk_comm_broadcast(h, dptr(b), 208, root))
+        torch.cuda.synchronize()
+        checks[f"broadcast_208_from_rank_{root}"] = bool(np.array_equal(b.cpu().numpy(), np.array([(7 * i + root) % 251 for i in range(208)], np.uint8)))
+    # 4. basic sumcheck with the whole-table absorb: ONE 2^20-entry table = four chunks of the streamed gather to rank 0
+    logn = 20
+    full = np.zeros((1 << logn, 4), np.uint64)
+    _lib.check(zk.lib().zk_host_fill_random(0, 0x5EED0F00, 0, 1 << logn, _lib.p64(full)))
+    shard = S.GpuShard.from_array(0, S.shard_of(full, rank, world))
+    cs, rp, ch = S.sumcheck_basic_prove_device(comm, shard, absorb_table=True)
+    wcs, wrp, wch = O.sumcheck_basic_prove(0, full)                            # the checker, on the whole table
+    checks["sharded_basic_sumcheck_with_absorb_equals_oracle"] = bool(np.array_equal(cs, wcs) and np.array_equal(rp, wrp) and np.array_equal(ch, wch))
+    point = full[:logn].copy()
+    checks["sharded_evaluate_equals_oracle"] = bool(np.array_equal(S.mle_evaluate(comm, shard.poly, point), O.evaluate(0, full, point)))
+    # 5. GKR sumcheck on 2 x 2 tables of 2^14 entries
+    lg = 14
+    tabs = np.zeros((2, 2, 1 << lg, 4), np.uint64)
+    for k in range(4):
+        _lib.check(zk.lib().zk_host_fill_random(0, 0x5EED0F10 + k, 0, 1 << lg, _lib.p64(tabs[k // 2, k % 2])))
+    claimed = O.vec_sum(0, O.sumpoly_reduce(0, tabs))
+    ss = S.GpuSumShard(0, [[zk.MultilinearPolynomial(0, S.shard_of(tabs[p, f], rank, world)) for f in range(2)] for p in range(2)])
+    co, gch, _ = S.sumcheck_gkr_prove_device(comm, ss, claimed, zk.Transcript())
+    wco, wgch = O.sumcheck_gkr_prove(0, tabs, claimed, O.Transcript())
+    checks["sharded_gkr_sumcheck_equals_oracle"] = bool(np.array_equal(co, wco) and np.array_equal(gch, wgch))
+    # 6. MSM: 2^12 terms sliced over the ranks, the identity of the structured bases on the whole
+    n = 1 << 12
+    per = n // world
+    a_lo = zk.from_ints(0, [SEED_MSM + rank * per * MSM_D])[0]
+    bases = zk.G1Bases.synthetic(per, a_lo, zk.from_ints(0, [MSM_D])[0])
+    sc = zk.MultilinearPolynomial.alloc(0, per)
+    _lib.check(zk.lib().zk_table_fill_random_strided(sc._h, SEED_MSM, rank * per, 1))
+    pt = S.msm_device(comm, sc, bases)
+    whole = zk.MultilinearPolynomial.alloc(0, n)
+    _lib.check(zk.lib().zk_table_fill_random_strided(whole._h, SEED_MSM, 0, 1))
+    checks["sharded_msm_identity"] = bool(msm_identity_check(zk, whole, SEED_MSM, MSM_D, pt))
+    mine = all(checks.values())
+    agreed = comm.all_gather(np.array([1 if mine else 0], np.uint64))
+    checks["every_rank_agrees"] = bool(np.asarray(agreed).reshape(-1).all())
+    return {"preflight": True, "ok": bool(all(checks.values())), "n_gpus": world, "collectives": env.collectives, "checks": checks,
+            "seconds": time.perf_counter() - t0}
 
 
 # ---- the fold (headline) ------------------------------------------------------------------------------------------------
@@ -735,8 +830,8 @@ def baseline_configs(zk, args):
     fold_ms = min(event_time_ms(lambda: _lib.check(L.zk_mle_fold(poly._h, 0, _lib.p64(r), dst._h, stream)), 400, warm=200, blocker=busy)
                   for _ in range(3))                    # the smallest of three: one run on a loaded host read 156 us for this 11-us launch
     del big, big_dst
+    zk.Prover.init(0, poly).prove()                          # (a Prover proves once: prove() appends to its own transcript, prover.rs:10,38-58)
     prover = zk.Prover.init(0, poly)
-    prover.prove()
     t0 = time.perf_counter()
     proof = prover.prove()
     prove_s = time.perf_counter() - t0

@@ -157,7 +157,8 @@ int zk_sumcheck_last_stats(zk_sumcheck_stats *out);
 /* Fault injection for tests: the NEXT proof (of any thread) whose transcript steps run on the host finds its host side deaf for
  * `milliseconds` -- as if the process had been descheduled.  The kernels waiting for their challenge give up after their spin
  * budget (2-3 s), every kernel still ends, and the proving call returns ZK_E_HIP with zk_last_error naming the cause; the
- * thread's next proof works.  The reference has no analogue (its prover cannot stall: it is one thread). */
+ * thread's next proof works.  The reference has no analogue (its prover cannot stall: it is one thread).  Process-global, so it is
+ * inert -- returns ZK_E_ARG -- unless the process runs with ZK_ENABLE_FAULT_INJECTION=1 in its environment. */
 int zk_debug_stall_service_once(int milliseconds);
 
 /* Prover::init + Prover::prove  prover.rs:22-71.  The table stays in HBM; per round one fused
@@ -166,6 +167,10 @@ int zk_debug_stall_service_once(int milliseconds);
  * (SumcheckProof.round_univariate_polynomials); challenges (nvars) is diagnostic, may be NULL. */
 int zk_sumcheck_basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys,
                             uint64_t *challenges);
+/* the same on the CALLER's transcript -- `Prover { transcript, .. }` is a public field of the reference's prover (prover.rs:7-13) that prove()
+ * appends to (:38-58): the transcript ends in the state the reference's ends in, whatever it had absorbed before */
+int zk_sumcheck_basic_prove_on(const zk_table *table, zk_transcript *transcript, uint64_t *claimed_sum, uint64_t *round_polys,
+                               uint64_t *challenges);
 /* Verifier::verify  verifier.rs:23-71 (its final `evaluate` is the same GPU fold); *ok = 1 / 0 */
 int zk_sumcheck_basic_verify(const zk_table *table, const uint64_t *claimed_sum,
                              const uint64_t *round_polys, size_t nrounds, int *ok);

@@ -93,6 +93,36 @@ def test_eight_rank_rehearsal_is_strong_scaling_of_one_table():
 
 
 @pytest.mark.gpu
+def test_preflight_exercises_every_collective_and_one_proof_of_each_kind():
+    # what the driver can run first on a multi-GPU node (seconds): here the ranks are threads of one process on the one GPU
+    p = run(["--gpus", "4", "--rehearse", "--preflight"])
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    d = last_json(p.stdout)
+    assert d["preflight"] is True and d["ok"] is True and d["n_gpus"] == 4 and d["seconds"] < 120
+    for k in ("all_reduce_i64_27_words_exact", "all_reduce_i64_1152_words_exact", "all_gather_rank_order", "broadcast_208_from_rank_0", "broadcast_208_from_rank_3",
+              "sharded_basic_sumcheck_with_absorb_equals_oracle", "sharded_evaluate_equals_oracle", "sharded_gkr_sumcheck_equals_oracle", "sharded_msm_identity",
+              "every_rank_agrees"):
+        assert d["checks"][k] is True, k
+    one = run(["--gpus", "1", "--preflight"])                # the same at one rank (no transport at all)
+    assert one.returncode == 0 and last_json(one.stdout)["ok"] is True
+
+
+@pytest.mark.gpu
+def test_config5_at_its_stated_size_eight_ranks_one_2p24_table():
+    # BASELINE config 5 as stated -- ONE 2^24-entry table and ONE 2^24-term MSM split 8 ways -- inside the suite: the 8 ranks are threads sharing the
+    # one GPU (not a scaling measurement); what the line checks must hold: the verifier's equations on the sharded proof, the same MSM point on every
+    # rank, the O(N) identity of the 2^24 MSM
+    p = run(["--gpus", "8", "--rehearse", "--log-n", "24", "--steps", "20", "--warmup", "5", "--msm-reps", "1", "--no-cpu-baseline", "--no-weak"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = last_json(p.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["entries_per_gpu"] == (1 << 24) // 8 and "failed_legs" not in d
+    c5 = d["config5_strong"]
+    assert c5["sumcheck"]["verifier_equations_hold"] is True and c5["sumcheck"]["rounds"] == 24
+    assert c5["msm"]["same_point_on_every_rank"] is True and c5["msm"]["post_check"]["holds"] is True
+    assert c5["msm_precomputed"]["same_point_as_plain"] is True
+
+
+@pytest.mark.gpu
 def test_a_stuck_secondary_leg_does_not_take_the_headline_with_it():
     # N > 1: the legs after the headline run collectives; past ZK_BENCH_LEG_DEADLINE the line is printed with what has finished (bench.py
     # secondary_legs_watchdog).  Here the deadline is shorter than the legs take, on the 8-rank rehearsal.

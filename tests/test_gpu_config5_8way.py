@@ -129,9 +129,11 @@ def test_one_rank_whose_host_side_stalls_does_not_hang_the_others():
     (zk_debug_stall_service_once).  Its kernels give up and end, the rank keeps its place in every collective, BOTH ranks return within
     seconds with an error -- the stalled one naming the cause, the other one told by the status word the ranks sum at the end -- and the
     next sharded proof on the same threads equals the oracle's."""
+    import os
     import time
     zk = G.import_package()
     from zkmle_amd import _lib
+    os.environ["ZK_ENABLE_FAULT_INJECTION"] = "1"             # the test hook is process-global: opt in (include/zkmle.h)
     S = zk.sharded
     field, world, logn = O.FR381, 2, 16
     table = fill(zk, field, 1 << logn, 0xC5_0400)
@@ -155,7 +157,10 @@ def test_one_rank_whose_host_side_stalls_does_not_hang_the_others():
         cs, rp, ch = S.sumcheck_basic_prove_device(comm, shard)
         return err, took, cs, rp, ch
 
-    outs = run_ranks(world, on_own_stream(zk, body))
+    try:
+        outs = run_ranks(world, on_own_stream(zk, body))
+    finally:
+        os.environ.pop("ZK_ENABLE_FAULT_INJECTION", None)
     errs = [o[0] for o in outs]
     assert all(e is not None for e in errs), ("the ranks must agree that the proof failed", errs)   # one status word summed at the end
     assert any("host" in e.lower() for e in errs) and all("host" in e.lower() or "another rank" in e.lower() for e in errs), errs

@@ -82,6 +82,32 @@ def test_basic_sumcheck_random_vs_oracle(zk, field, logn):
     assert zk.Verifier.init().verify(proof) is True
 
 
+@pytest.mark.parametrize("field,logn", [(0, 3), (0, 13), (2, 16)])
+def test_prover_transcript_field_ends_where_the_reference_leaves_it(zk, field, logn):
+    """`Prover { transcript, .. }` is a public field the reference's prove() appends to (prover.rs:10, :38-58): after prove() it has absorbed
+    the table, the claimed sum and every round message, and has sampled every challenge.  Replayed here append by append on a second
+    transcript (fiat_shamir_transcript.rs:22-43): both must give the same next sample -- and so must a prover whose transcript had already
+    absorbed something (zk_sumcheck_basic_prove_on runs on the caller's sponge)."""
+    table = rand_table(zk, field, 1 << logn, 4000 + logn)
+    for prefix in (b"", b"state the caller left"):
+        prover = zk.Prover.init(field, table)
+        replay = zk.Transcript()
+        if prefix:
+            prover.transcript.append(prefix)
+            replay.append(prefix)
+        proof = prover.prove()
+        replay.append(prover.initial_polynomial.convert_to_bytes())                       # :38-39
+        replay.append(O.fe_to_bytes_be(field, proof.initial_claimed_sum))                 # :40-41
+        for k in range(logn):
+            replay.append(O.fe_to_bytes_be(field, proof.round_univariate_polynomials[k, 0]) +
+                          O.fe_to_bytes_be(field, proof.round_univariate_polynomials[k, 1]))   # :51-55
+            assert np.array_equal(replay.random_challenge_as_field_element(field), prover.challenges[k])   # :58
+        assert prover.transcript.sample_random_challenge() == replay.sample_random_challenge()
+        if not prefix:
+            cs, rp, _ = O.sumcheck_basic_prove(field, table)
+            assert np.array_equal(proof.initial_claimed_sum, cs) and np.array_equal(proof.round_univariate_polynomials.reshape(rp.shape), rp)
+
+
 def test_basic_sumcheck_config2_2p20_random(zk):
     """BASELINE config 2 size (20 variables, random table): proof equals the oracle's"""
     field, logn = 0, 20

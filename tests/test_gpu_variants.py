@@ -48,21 +48,23 @@ def test_host_side_stall_fails_the_proof_and_the_next_one_works():
     L.check(lib.zk_init(0))
     if os.environ.get("ZK_HOST_TRANSCRIPT") == "0":
         pytest.skip("the transcript step runs on the device in this environment")
+    os.environ.pop("ZK_ENABLE_FAULT_INJECTION", None)
+    assert lib.zk_debug_stall_service_once(1) != 0              # the hook is process-global: it only arms where the environment asks for it
+    os.environ["ZK_ENABLE_FAULT_INJECTION"] = "1"
     n = 1 << 15
     poly = zk.MultilinearPolynomial.random(0, n, 0xFA17)
     table = poly.evaluated_values
     want = O.sumcheck_basic_prove(0, table)
-    prover = zk.Prover.init(0, poly)
-    assert np.array_equal(prover.prove().round_univariate_polynomials, want[1])
+    assert np.array_equal(zk.Prover.init(0, poly).prove().round_univariate_polynomials, want[1])
     L.check(lib.zk_debug_stall_service_once(3500))
     t0 = time.time()
     with pytest.raises(zk.ZkError) as ei:
-        prover.prove()
+        zk.Prover.init(0, poly).prove()
     took = time.time() - t0
     assert took < 10.0, took
     assert "host" in str(ei.value).lower() or "host" in lib.zk_last_error().decode().lower(), str(ei.value)
     for _ in range(2):                                           # the thread's mailbox, service thread and arrival counters are usable again
-        proof = prover.prove()
+        proof = zk.Prover.init(0, poly).prove()
         assert np.array_equal(proof.initial_claimed_sum, want[0]) and np.array_equal(proof.round_univariate_polynomials, want[1])
     tabs = np.stack([np.stack([zk.MultilinearPolynomial.random(0, 1 << 12, 0xFA20 + 2 * p + f).evaluated_values for f in range(2)]) for p in range(2)])
     claimed = O.vec_sum(0, O.sumpoly_reduce(0, tabs))
@@ -73,3 +75,4 @@ def test_host_side_stall_fails_the_proof_and_the_next_one_works():
         zk.sumcheck.prove(sp, claimed, zk.Transcript())
     res = zk.sumcheck.prove(sp, claimed, zk.Transcript())
     assert np.array_equal(res.round_univariate_polynomials, co) and np.array_equal(res.random_challenges, ch)
+    os.environ.pop("ZK_ENABLE_FAULT_INJECTION", None)

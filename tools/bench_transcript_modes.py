@@ -23,10 +23,10 @@ for lg in (12, 16, 20, 22):
     del tabs, sp
 for lg in (20, 24):
     poly = zk.MultilinearPolynomial.random(0, 1 << lg, 0x5EED0002)
-    pr = zk.Prover.init(0, poly)
-    pr.prove()
+    zk.Prover.init(0, poly).prove()
     ms = []
     for _ in range(3):
+        pr = zk.Prover.init(0, poly)
         pr.prove()
         ms.append(zk.sumcheck.last_stats()["ms_rounds"])
     out[f"basic_sumcheck_2p{lg}_rounds_ms"] = sorted(ms)[len(ms) // 2]

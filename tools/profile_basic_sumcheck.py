@@ -6,7 +6,6 @@ zk = G.import_package()
 from zkmle_amd import _lib
 _lib.check(zk.lib().zk_init(0))
 poly = zk.MultilinearPolynomial.random(0, 1 << 24, 0x5EED0002)
-pr = zk.Prover.init(0, poly)
 for _ in range(6):
-    pr.prove()
+    zk.Prover.init(0, poly).prove()
 print(zk.sumcheck.last_stats())

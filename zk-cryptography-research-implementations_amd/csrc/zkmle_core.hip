@@ -161,7 +161,14 @@ int pinned_pair(size_t bytes, void *out[2]) {
 struct PoolBlock { void *p; size_t cap; int dev; bool busy; hipStream_t stream; };   // stream = the one its last user ran on
 static std::vector<PoolBlock> g_pool;
 static size_t g_pool_bytes = 0;
-static const size_t kPoolLimit = (size_t)96 << 30;      // cached + in-use scratch per process (a third of the 288 GB of HBM)
+// cached + in-use scratch per process: a third of the current device's memory (96 GB of an MI355X's 288), asked of the device the first time it matters
+static size_t pool_limit() {
+    static const size_t v = [] {
+        size_t free_b = 0, total_b = 0;
+        return hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b / 3 : (size_t)96 << 30;
+    }();
+    return v;
+}
 
 int pool_alloc(size_t bytes, void **out) {
     if (bytes == 0) bytes = 16;
@@ -174,9 +181,15 @@ int pool_alloc(size_t bytes, void **out) {
             if (!b.busy && b.dev == dev && b.stream == cur_stream() && b.cap >= bytes && b.cap <= 2 * bytes + (1u << 20) && (!best || b.cap < best->cap)) best = &b;
         if (best) { best->busy = true; *out = best->p; return ZK_OK; }
     }
-    if (g_pool_bytes + bytes > kPoolLimit) ZK_TRY(zk_release_cached_memory());
+    if (g_pool_bytes + bytes > pool_limit()) ZK_TRY(zk_release_cached_memory());
     void *p = nullptr;
-    ZK_HIP(hipMalloc(&p, bytes));
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory) {                         // blocks cached for other streams / sizes may be what is in the way: give them back and try once more
+        (void)hipGetLastError();
+        ZK_TRY(zk_release_cached_memory());
+        e = hipMalloc(&p, bytes);
+    }
+    ZK_HIP(e);
     std::lock_guard<std::mutex> lk(g_mu);
     g_pool.push_back(PoolBlock{p, bytes, dev, true, cur_stream()});
     g_pool_bytes += bytes;

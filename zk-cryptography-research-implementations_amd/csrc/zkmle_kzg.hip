@@ -159,9 +159,22 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
     // wide windows (msm_sort_wide.cuh): c > 16 -- more buckets than one workgroup's LDS counts -- and every MSM on precomputed
     // window-shifted bases (`pre`: d_bases = [w][i], all windows feed ONE bucket set).  ZK_MSM_WIDE=1 forces the wide sort for c <= 16.
     static const bool force_wide = [] { const char *e = getenv("ZK_MSM_WIDE"); return e && e[0] == '1'; }();
-    const bool wide = !shifted && (c > 16 || pre || (force_wide && c >= 9));
+    bool wide = !shifted && (c > 16 || pre || (force_wide && c >= 9));
     if (c < 2 || c > (wide ? 24 : 16)) return ZK_E_ARG;
     const unsigned nwin1 = (256 + c - 1) / c, nb = 1u << (c - 1);
+    // (ZK_MSM_WIDE=1 on a window whose first sort level has more bins than the wide sort takes: the LDS sort, which holds any c <= 16)
+    if (wide && c <= 16 && !pre && (nwin1 << 7) > 2048) wide = false;
+    // A window far wider than the MSM is long asks for bucket and reduction arrays of tens of GB to add a handful of points (c = 24: 11 x 2^23
+    // buckets, two arrays of 192 B each: ~35 GB whatever n is).  On this GPU's 288 GB that works (the tests run it); where it would not fit in
+    // half of the memory that is free, the call is refused with the reason instead of dying in an allocation.
+    if (c > 16 && (size_t)nb > 64 * (n_sub ? n_sub : 1)) {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)(pre ? 1u : nwin1) * nb * 2 * sizeof(G1Xyzz);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 2) {
+            set_last_error("zk_msm_g1: window_bits this wide for so few terms needs more bucket memory than half of what is free; use 0 (automatic) or a narrower window");
+            return ZK_E_ARG;
+        }
+    }
     if (n * ((shifted || pre) ? nwin1 : 1) >= ((size_t)1 << 31)) return ZK_E_ARG;   // index + sign are packed in 32 bits
     const unsigned nwin = shifted ? batch : pre ? 1u : nwin1;          // bucket sets
     const size_t nbuckets = (size_t)nwin * nb;

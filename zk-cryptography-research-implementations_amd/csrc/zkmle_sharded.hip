@@ -13,6 +13,7 @@
 #include <time.h>
 
 #include <condition_variable>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -130,6 +131,7 @@ struct zk_comm_local_group {
     int arrived = 0;
     uint64_t generation = 0;
     bool aborted = false;
+    std::atomic<int> ends{0};                              // communicators made from this group and not yet freed
     std::vector<const void *> ptr;
     explicit zk_comm_local_group(int n) : nranks(n), ptr((size_t)n, nullptr) {}
     int barrier() {
@@ -199,6 +201,7 @@ struct zk_comm {
     uint64_t bytes_rx, ncoll;
     std::vector<uint8_t> hs, hr;     // host staging of the callback kind
     LocalEnd *local = nullptr;
+    bool in_step = false;            // set once a sharded proof has been through its last exchange (sharded_rounds), cleared by the entry points
 
     int all_reduce_i64(void *dev, size_t count) {
         ncoll++;
@@ -401,6 +404,7 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
         uint64_t f = rc != ZK_OK ? 1 : 0;
         ZK_HIP(memcpy_on_stream(flag.p, &f, 8, hipMemcpyHostToDevice));
         ZK_TRY(c->all_reduce_i64(flag.p, 1));
+        c->in_step = true;                                 // every collective of the proof ran on this rank: an error from here on is an AGREED one
         ZK_HIP(memcpy_on_stream(&f, flag.p, 8, hipMemcpyDeviceToHost));
         if (rc != ZK_OK) { set_last_error(mine); return rc; }
         if (f != 0) { set_last_error("sharded proof: another rank's proof failed (its host-assisted transcript step stalled or a kernel gave up): this rank's proof is not valid"); return ZK_E_COMM; }
@@ -437,9 +441,7 @@ int sharded_rounds(zk_comm *c, int field, int mode, const zk_table *const *tabs,
                 if (xl) {
                     ZK_TRY(c->all_reduce_i64(lp, ((size_t)1 << m) * W));   // the only exchange of these m rounds, on the stream
                     ZK_TRY(zk_rounds_multi_absorb(r, lp, m));
-                } else {
-                    c->ncoll++;                                            // (counted as the pass's exchange: zk_comm_stats)
-                }
+                }                                                          // (one rank: no exchange ran, none is counted -- zk_comm_stats)
                 const size_t n = L >> m;
                 const unsigned mn = n * G > kTail ? pass(n * G) : 0u;
                 ZK_TRY(zk_rounds_multi_fold_evals(r, one, dst->t[0], m, mn, xl));
@@ -548,12 +550,26 @@ int zk_comm_from_host_ops(const zk_comm_host_ops *ops, int nranks, int rank, zk_
     *out = new zk_comm{1, nranks, rank, nullptr, *ops, 0, 0, {}, {}};
     return ZK_OK;
 }
+// The ranks-as-threads barrier has no timeout: a rank that returns early from a sharded call (an allocation that failed, a bad argument)
+// would leave its peers waiting in the next exchange for ever.  Every sharded entry point therefore aborts the group when it returns an
+// error BEFORE its last exchange; the peers come back with ZK_E_COMM.  (RCCL and caller-supplied callbacks have their own failure paths.)
+// (A failure the ranks AGREED on -- the status word summed at the end of a sharded proof -- left every rank in step: the group stays usable.)
+static int local_group_fail(zk_comm *c, int rc) {
+    if (rc != ZK_OK && c && c->local && !c->in_step) c->local->g->abort();
+    if (c) c->in_step = false;
+    return rc;
+}
 int zk_comm_local_group_new(int nranks, zk_comm_local_group **out) {
     if (!out || nranks < 1 || nranks > 1024) return ZK_E_ARG;
     *out = new zk_comm_local_group(nranks);
     return ZK_OK;
 }
 int zk_comm_local_group_free(zk_comm_local_group *g) {
+    if (!g) return ZK_OK;
+    if (g->ends.load() != 0) {                              // an end still points into the group: freeing it now would be a use after free
+        set_last_error("zk_comm_local_group_free: free every communicator made from the group first (zk_comm_free)");
+        return ZK_E_ARG;
+    }
     delete g;
     return ZK_OK;
 }
@@ -568,12 +584,14 @@ int zk_comm_from_local_group(zk_comm_local_group *g, int rank, zk_comm **out) {
     zk_comm_host_ops ops{e, local_all_reduce, local_all_gather, local_gather, local_broadcast};
     zk_comm *c = new zk_comm{1, g->nranks, rank, nullptr, ops, 0, 0, {}, {}};
     c->local = e;
+    g->ends++;
     *out = c;
     return ZK_OK;
 }
 int zk_comm_free(zk_comm *c) {
     if (!c) return ZK_OK;
     if (c->kind == 0 && c->nccl) (void)rccl().CommDestroy(c->nccl);
+    if (c->local) c->local->g->ends--;
     delete c->local;
     delete c;
     return ZK_OK;
@@ -615,7 +633,7 @@ int zk_comm_broadcast(zk_comm *c, void *dev_buf, size_t bytes, int root) {
     return c->broadcast(dev_buf, bytes, root);
 }
 
-int zk_sharded_sumcheck_basic_prove(zk_comm *c, const zk_table *shard, int absorb_table, uint64_t *claimed_sum, uint64_t *round_polys,
+static int sharded_sumcheck_basic_prove_impl(zk_comm *c, const zk_table *shard, int absorb_table, uint64_t *claimed_sum, uint64_t *round_polys,
                                     uint64_t *challenges) {
     if (!c || !shard || !claimed_sum || !round_polys) return ZK_E_ARG;
     if (!is_pow2(shard->len)) return ZK_E_NOT_POW2;                       // Prover::init -> MultilinearPolynomial::new (prover.rs:23)
@@ -630,8 +648,14 @@ int zk_sharded_sumcheck_basic_prove(zk_comm *c, const zk_table *shard, int absor
     const zk_table *tabs[1] = {shard};
     return sharded_rounds(c, shard->field, 0, tabs, 1, 1, &t, claimed_sum, round_polys, challenges, nullptr);
 }
+int zk_sharded_sumcheck_basic_prove(zk_comm *c, const zk_table *shard, int absorb_table, uint64_t *claimed_sum, uint64_t *round_polys,
+                                    uint64_t *challenges) {
+    const int rc = sharded_sumcheck_basic_prove_impl(c, shard, absorb_table, claimed_sum, round_polys, challenges);
+    return local_group_fail(c, rc);
+}
 
-int zk_sharded_sumcheck_gkr_prove(zk_comm *c, const zk_table *const *shards, size_t nprod, size_t nfac, const uint64_t *claimed_sum,
+
+static int sharded_sumcheck_gkr_prove_impl(zk_comm *c, const zk_table *const *shards, size_t nprod, size_t nfac, const uint64_t *claimed_sum,
                                   zk_transcript *t, uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values) {
     if (!c || !shards || !claimed_sum || !t || !round_coeffs || !challenges) return ZK_E_ARG;
     if (nprod == 0 || nfac == 0 || nprod * nfac > 64) return ZK_E_ARG;
@@ -656,8 +680,14 @@ int zk_sharded_sumcheck_gkr_prove(zk_comm *c, const zk_table *const *shards, siz
     if (nprod < 2 || nfac < 2) return ZK_E_NEED_TWO;                      // generate_round_univariate panics (sum_polynomial.rs:58-61)
     return sharded_rounds(c, field, 1, shards, nprod, nfac, t, nullptr, round_coeffs, challenges, final_values);
 }
+int zk_sharded_sumcheck_gkr_prove(zk_comm *c, const zk_table *const *shards, size_t nprod, size_t nfac, const uint64_t *claimed_sum,
+                                  zk_transcript *t, uint64_t *round_coeffs, uint64_t *challenges, uint64_t *final_values) {
+    const int rc = sharded_sumcheck_gkr_prove_impl(c, shards, nprod, nfac, claimed_sum, t, round_coeffs, challenges, final_values);
+    return local_group_fail(c, rc);
+}
 
-int zk_sharded_mle_evaluate(zk_comm *c, const zk_table *shard, const uint64_t *values, size_t nvalues, uint64_t *out) {
+
+static int sharded_mle_evaluate_impl(zk_comm *c, const zk_table *shard, const uint64_t *values, size_t nvalues, uint64_t *out) {
     if (!c || !shard || (!values && nvalues) || !out) return ZK_E_ARG;
     if (!is_pow2(shard->len) || !is_pow2((size_t)c->nranks)) return ZK_E_NOT_POW2;
     ZK_TRY(require_device());
@@ -677,8 +707,13 @@ int zk_sharded_mle_evaluate(zk_comm *c, const zk_table *shard, const uint64_t *v
     zk_table rep{field, G, all.p, 0};
     return zk_mle_evaluate(&rep, values + m * L64, k, out);
 }
+int zk_sharded_mle_evaluate(zk_comm *c, const zk_table *shard, const uint64_t *values, size_t nvalues, uint64_t *out) {
+    const int rc = sharded_mle_evaluate_impl(c, shard, values, nvalues, out);
+    return local_group_fail(c, rc);
+}
 
-int zk_sharded_msm_g1(zk_comm *c, const zk_table *scalars_slice, const zk_g1_bases *bases_slice, int window_bits, uint64_t *out12,
+
+static int sharded_msm_g1_impl(zk_comm *c, const zk_table *scalars_slice, const zk_g1_bases *bases_slice, int window_bits, uint64_t *out12,
                       zk_msm_stats *stats) {
     if (!c || !scalars_slice || !bases_slice || !out12) return ZK_E_ARG;
     uint64_t mine[12];
@@ -701,13 +736,19 @@ int zk_sharded_msm_g1(zk_comm *c, const zk_table *scalars_slice, const zk_g1_bas
     memcpy(out12, acc, 96);
     return ZK_OK;
 }
+int zk_sharded_msm_g1(zk_comm *c, const zk_table *scalars_slice, const zk_g1_bases *bases_slice, int window_bits, uint64_t *out12,
+                      zk_msm_stats *stats) {
+    const int rc = sharded_msm_g1_impl(c, scalars_slice, bases_slice, window_bits, out12, stats);
+    return local_group_fail(c, rc);
+}
+
 
 // open_and_prove (multilinear_kzg.rs:50-126) of a low-bit-sharded table.  Proof i < m (the local variables): quotient and pre-summed
 // bases of round i pair global indices that share their low bits, so pi_i = sum over the ranks of a LOCAL MSM (local quotient x the
 // opening key of the rank's own bases P_{jG+g}) -- one all-gather of m points per rank and G - 1 additions per proof.  The last k
 // proofs come from the G-entry table of leftovers (one per rank) against the per-rank totals of the bases, both all-gathered, and
 // are computed replicated.
-int zk_sharded_kzg_open(zk_comm *c, const zk_table *shard, const zk_g1_bases *bases_local, const zk_kzg_opening_key *key_local,
+static int sharded_kzg_open_impl(zk_comm *c, const zk_table *shard, const zk_g1_bases *bases_local, const zk_kzg_opening_key *key_local,
                         const uint64_t *opening, size_t nopen, uint64_t *evaluation, uint64_t *proofs) {
     if (!c || !shard || !bases_local || !opening || !evaluation || !proofs) return ZK_E_ARG;
     if (shard->field != ZK_FR381) return ZK_E_ARG;
@@ -771,5 +812,11 @@ int zk_sharded_kzg_open(zk_comm *c, const zk_table *shard, const zk_g1_bases *ba
     zk_g1_bases_free(b);
     return rc;
 }
+int zk_sharded_kzg_open(zk_comm *c, const zk_table *shard, const zk_g1_bases *bases_local, const zk_kzg_opening_key *key_local,
+                        const uint64_t *opening, size_t nopen, uint64_t *evaluation, uint64_t *proofs) {
+    const int rc = sharded_kzg_open_impl(c, shard, bases_local, key_local, opening, nopen, evaluation, proofs);
+    return local_group_fail(c, rc);
+}
+
 
 }  // extern "C"

@@ -138,7 +138,11 @@ static ServiceWorker &service_worker() {
     return w;
 }
 static std::atomic<int> g_stall_service_ms{0};               // zk_debug_stall_service_once
-static thread_local bool g_last_proof_clean = false;        // the last proof of this thread saw every kernel's last post: nothing on the stream looks at the mailbox
+// The last proof of this thread saw every kernel's last post: nothing on ITS stream looks at ITS mailbox any more.  The mailbox is per (thread,
+// device) and the kernels that may still poll it sit on the stream that proof ran on, so the mark names both: a proof on another device or
+// another stream of this thread does not make a mailbox it never touched safe to reset.
+struct CleanProofMark { const void *mbox = nullptr; hipStream_t stream = nullptr; bool clean = false; };
+static thread_local CleanProofMark g_last_proof;
 static thread_local int g_host_rounds_active = 0;           // one proof at a time per proving thread owns the mailbox and the worker
 
 // Whether the transcript step of a round runs on the host thread that drives the proof (dev_transcript.cuh HostMailbox: default) or on
@@ -200,8 +204,8 @@ template <class F> struct DeviceRounds {
             mb_dev = (HostMailbox *)d;
             // nothing of an earlier proof may still be looking at the mailbox: a proof that ended cleanly has seen every kernel's last post
             // (collect); anything else on this thread's stream -- a proof that failed, other work -- is waited for
-            if (!g_last_proof_clean) ZK_HIP(stream_wait_idle());
-            g_last_proof_clean = false;
+            if (!(g_last_proof.clean && g_last_proof.mbox == h && g_last_proof.stream == cur_stream())) ZK_HIP(stream_wait_idle());
+            g_last_proof.clean = false;
             memset((void *)mb, 0, offsetof(HostMailbox, big));
             htr = &tr;
             hs.assign(nslots, fe_zero<F>());
@@ -556,7 +560,7 @@ template <class F> struct DeviceRounds {
             if (rc != ZK_OK || mb->aborted) (void)sync_words_reset();     // a pass that gave up may have left its arrival counter half-way
             if (rc != ZK_OK) { set_last_error("host-assisted transcript step: the device did not post a round (aborted or stalled)"); return rc; }
             if (mb->aborted) { set_last_error("host-assisted transcript step: a kernel gave up waiting for the host"); return ZK_E_HIP; }
-            g_last_proof_clean = !trace;
+            g_last_proof = CleanProofMark{(const void *)mb, cur_stream(), !trace};
             if (traced_len) print_tail_trace(traced_len);
             if (nfin_traced) print_fin_trace();
             return ZK_OK;                                   // `tr` is the sponge the steps ran on
@@ -619,11 +623,10 @@ int fold_pass(const void *in, void *out, size_t n, int k, const void *const *rp,
 }
 
 // ---- basic sumcheck prover: prover.rs:22-71 ----------------------------------------------------------
-template <class F> int basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64_t *round_polys, uint64_t *challenges) {
+template <class F> int basic_prove(const zk_table *table, Transcript &tr, uint64_t *claimed_sum, uint64_t *round_polys, uint64_t *challenges) {
     const size_t esz = 4 * F::N, L64 = F::N / 2;
     size_t len = table->len;
     unsigned nvars = ilog2(len);
-    Transcript tr;
     double t0 = now_ms();
     ZK_TRY(absorb_table<F>(tr, table->dptr, len));                     // :38-39
     double t1 = now_ms();
@@ -1339,6 +1342,8 @@ int zk_uni_lagrange_interpolate(int field, const uint64_t *xs, const uint64_t *y
 }
 
 int zk_debug_stall_service_once(int milliseconds) {
+    // fault injection: process-global, so it only arms in a process that asked for it
+    { const char *e = getenv("ZK_ENABLE_FAULT_INJECTION"); if (!(e && e[0] == '1')) { set_last_error("zk_debug_stall_service_once: set ZK_ENABLE_FAULT_INJECTION=1 in the environment to use the test hook"); return ZK_E_ARG; } }
     if (milliseconds < 0) return ZK_E_ARG;
     g_stall_service_ms.store(milliseconds);
     return ZK_OK;
@@ -1354,7 +1359,15 @@ int zk_sumcheck_basic_prove(const zk_table *table, uint64_t *claimed_sum, uint64
     if (!table || !claimed_sum || !round_polys) return ZK_E_ARG;
     if (!is_pow2(table->len)) return ZK_E_NOT_POW2;      // Prover::init -> MultilinearPolynomial::new (prover.rs:23)
     ZK_TRY(require_device());
-    ZK_DISPATCH_FIELD(table->field, return basic_prove<F>(table, claimed_sum, round_polys, challenges));
+    Transcript tr;                                         // Prover::init: Transcript::new() (prover.rs:24)
+    ZK_DISPATCH_FIELD(table->field, return basic_prove<F>(table, tr, claimed_sum, round_polys, challenges));
+    return ZK_OK;
+}
+int zk_sumcheck_basic_prove_on(const zk_table *table, zk_transcript *transcript, uint64_t *claimed_sum, uint64_t *round_polys, uint64_t *challenges) {
+    if (!table || !transcript || !claimed_sum || !round_polys) return ZK_E_ARG;
+    if (!is_pow2(table->len)) return ZK_E_NOT_POW2;
+    ZK_TRY(require_device());
+    ZK_DISPATCH_FIELD(table->field, return basic_prove<F>(table, transcript->t, claimed_sum, round_polys, challenges));
     return ZK_OK;
 }
 int zk_sumcheck_basic_verify(const zk_table *table, const uint64_t *claimed_sum, const uint64_t *round_polys, size_t nrounds, int *ok) {

@@ -31,6 +31,7 @@ def _decl():
         "zk_uni_evaluate": [C.c_int, u64p, sz, u64p, u64p],
         "zk_uni_lagrange_interpolate": [C.c_int, u64p, u64p, sz, u64p],
         "zk_sumcheck_basic_prove": [vp, u64p, u64p, u64p],
+        "zk_sumcheck_basic_prove_on": [vp, vp, u64p, u64p, u64p],
         "zk_sumcheck_basic_verify": [vp, u64p, u64p, sz, C.POINTER(C.c_int)],
         "zk_sumpoly_evaluate": [C.POINTER(vp), sz, sz, u64p, sz, u64p],
         "zk_sumpoly_reduce": [C.POINTER(vp), sz, sz, vp],
@@ -313,6 +314,7 @@ class Prover:
             self.initial_polynomial = MultilinearPolynomial(field, polynomial_evaluated_values)
         self.field = field
         self.initial_claimed_sum = self.initial_polynomial.sum()        # :28
+        self.transcript = Transcript()                                  # :24, a public field of the reference's Prover (:10)
         self.round_univariate_polynomials = None
         self.challenges = None
         self.is_initialized = True
@@ -326,7 +328,7 @@ class Prover:
         cs = np.zeros(Lm, np.uint64)
         rp = np.zeros((max(n, 1), 2, Lm), np.uint64)
         ch = np.zeros((max(n, 1), Lm), np.uint64)
-        L.check(_decl().zk_sumcheck_basic_prove(self.initial_polynomial._h, L.p64(cs), L.p64(rp), L.p64(ch)))
+        L.check(_decl().zk_sumcheck_basic_prove_on(self.initial_polynomial._h, self.transcript._h, L.p64(cs), L.p64(rp), L.p64(ch)))   # appends to self.transcript (:38-58)
         assert np.array_equal(cs, self.initial_claimed_sum)
         self.round_univariate_polynomials = rp[:n]
         self.challenges = ch[:n]
