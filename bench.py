@@ -752,9 +752,22 @@ def msm_roofline(st):
     adds = float(st["entries"])                             # one mixed addition per (term, window) entry with a non-zero digit
     achieved = adds * MADS_PER_MIXED_ADD / (st["ms_buckets"] * 1e-3)
     peak, src = measured_mad_peak()
-    return {"bound": "valu v_mad_u64_u32", "kernel": "msm_bucket_sum_kernel", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "Tmad/s",
-            "frac": achieved / peak, "mixed_adds": adds, "mads_per_mixed_add": MADS_PER_MIXED_ADD, "kernel_ms": st["ms_buckets"],
-            "peak_source": src, "traffic": None}
+    out = {"bound": "valu v_mad_u64_u32", "kernel": "msm_bucket_sum_kernel", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "Tmad/s",
+           "frac": achieved / peak, "mixed_adds": adds, "mads_per_mixed_add": MADS_PER_MIXED_ADD, "kernel_ms": st["ms_buckets"],
+           "peak_source": src, "traffic": None}
+    # the kernel's memory side, for completeness: HBM bytes per launch from the committed PMC passes of the same 2^24 workload (16-bit windows,
+    # or one bucket set of 22-bit windows on precomputed bases), scaled by the additions of this launch
+    name = "msm_2p24_c22pre_bucket_pmc.json" if st.get("window_bits", 16) > 16 else "msm_2p24_c16_bucket_pmc.json"
+    pmc = os.path.join(ROOT, "profiles", "r4", name)
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            d = json.load(f)
+        per_add = d["hbm_bytes_per_launch"] / (d["algorithmic_bytes_per_launch"] / 128.0)
+        out["traffic"] = per_add * adds
+        out["traffic_GBps"] = per_add * adds / (st["ms_buckets"] * 1e-3) / 1e9
+        out["traffic_over_128B_per_add"] = d["traffic_over_algorithmic"]
+        out["traffic_source"] = f"profiles/r4/{name} (committed summary of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a 2^24-term MSM; bytes per mixed addition x this launch's additions)"
+    return out
 
 
 _MAD_PEAK = None
