@@ -192,9 +192,25 @@ __device__ __forceinline__ FqU quad_sel(unsigned q, const FqU &a0, const FqU &a1
     for (int i = 0; i < UParams<Fq381>::L; i++) r.l[i] = q == 0 ? a0.l[i] : (q == 1 ? a1.l[i] : (q == 2 ? a2.l[i] : a3.l[i]));
     return r;
 }
+// The lanes of a wave run the quad operations in LOCKSTEP: no lane leaves early.  r4: with `if (a.inf) return a;` in front of the stages, a wave in which
+// some quads held infinity and others did not produced wrong doublings in the quads that went on (tools/test_quad_ops.hip reproduces it: a branch in
+// front of the quad_perm moves); r3's kernels only ever met all-infinity or no-infinity waves there.  So every lane computes every stage -- the all-zero
+// record goes through the formulas as zeros -- and the cases are SELECTED at the end, limb by limb; the one real branch left (equal x: doubling /
+// cancellation, redone exactly by every lane alone) comes after the last cross-lane move.
+__device__ __forceinline__ FqU fqu_select(bool c, const FqU &a, const FqU &b) {
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < UParams<Fq381>::L; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+__device__ __forceinline__ G1XyzzU g1u_select(bool c, const G1XyzzU &a, const G1XyzzU &b) {
+    G1XyzzU r;
+    r.x = fqu_select(c, a.x, b.x); r.y = fqu_select(c, a.y, b.y); r.zz = fqu_select(c, a.zz, b.zz); r.zzz = fqu_select(c, a.zzz, b.zzz);
+    r.inf = c ? a.inf : b.inf;
+    return r;
+}
 __device__ __forceinline__ G1XyzzU g1u_dbl_quad(const G1XyzzU &a, unsigned q) {
     using F = Fq381;
-    if (a.inf) return a;
     const FqU u = uadd<F>(a.y, a.y);
     // stage 1: V = U^2 | XX = X^2
     FqU t = umul<F>(quad_sel(q, u, a.x, u, a.x), quad_sel(q, u, a.x, u, a.x));
@@ -215,12 +231,10 @@ __device__ __forceinline__ G1XyzzU g1u_dbl_quad(const G1XyzzU &a, unsigned q) {
     o.zz = zz3;
     o.zzz = zzz3;
     o.inf = false;
-    return o;
+    return g1u_select(a.inf, a, o);
 }
 __device__ __forceinline__ G1XyzzU g1u_add_quad(const G1XyzzU &a, const G1XyzzU &b, unsigned q) {
     using F = Fq381;
-    if (a.inf) return b;
-    if (b.inf) return a;
     // stage 1: U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1
     FqU t = umul<F>(quad_sel(q, a.x, b.x, a.y, b.y), quad_sel(q, b.zz, a.zz, b.zzz, a.zzz));
     const FqU u1 = quad_bcast<0>(t), u2 = quad_bcast<1>(t), s1 = quad_bcast<2>(t), s2 = quad_bcast<3>(t);
@@ -231,9 +245,6 @@ __device__ __forceinline__ G1XyzzU g1u_add_quad(const G1XyzzU &a, const G1XyzzU 
     // stage 3: PPP' = P' PP | Q = U1 PP | ZZ3 = ZZ12 PP
     t = umul<F>(quad_sel(q, pn, u1, zz12, zz12), pp);
     const FqU pppn = quad_bcast<0>(t), qq = quad_bcast<1>(t), zz3 = quad_bcast<2>(t);
-    if (u_is_zero_mod_p<F>(zz3)) {                     // the same x coordinate (rare): every lane redoes it alone, exactly
-        if (fqu_is_zero(pn)) return fqu_is_zero(rn) ? g1u_dbl(a) : g1u_inf();
-    }
     const FqU x3 = usub<F>(uadd<F>(rr, pppn), uadd<F>(qq, qq));
     // stage 4: R' (X3 - Q) | S1 PPP' | ZZZ12 PPP'
     t = umul<F>(quad_sel(q, rn, s1, zzz12, zzz12), quad_sel(q, usub<F>(x3, qq), pppn, pppn, pppn));
@@ -244,7 +255,11 @@ __device__ __forceinline__ G1XyzzU g1u_add_quad(const G1XyzzU &a, const G1XyzzU 
     o.zz = zz3;
     o.zzz = usub<F>(u_zero<F>(), z3);
     o.inf = false;
-    return o;
+    // behind the last cross-lane move: two finite operands with the same x coordinate (rare) are redone exactly by every lane alone
+    if (!a.inf && !b.inf && u_is_zero_mod_p<F>(zz3)) {
+        if (fqu_is_zero(pn)) o = fqu_is_zero(rn) ? g1u_dbl(a) : g1u_inf();
+    }
+    return g1u_select(a.inf, b, g1u_select(b.inf, a, o));
 }
 
 // internal accumulator -> stored XYZZ (canonical 32-bit Montgomery limbs)

@@ -502,6 +502,7 @@ constexpr size_t kXyzzUBytes = 256;   // one XYZZ point in the internal form (g1
 int launch_msm_plain_level(void *A, void *B, unsigned nwin, unsigned cm1, unsigned k, size_t hh, size_t lh, hipStream_t s);
 int launch_msm_gather_cd(const void *A, const void *B, unsigned nwin, unsigned cm1, unsigned k, unsigned mbits, void *X, hipStream_t s);
 int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsigned mbits, void *out, hipStream_t s);
+int launch_msm_weighted_bits(void *X, void *Y, unsigned narrays, unsigned mbits, void *S, hipStream_t s);   // the same sums by the bits of the weight (mbits <= 8; r4)
 int launch_msm_weighted_tail(void *X, void *Y, unsigned narrays, unsigned mbits, hipStream_t s);   // all weighted levels of the short arrays (the wide first ones grid-wide)
 int launch_msm_window_sums(const void *A, const void *R, unsigned nwin, unsigned c, void *out, hipStream_t s);
 int launch_g1_bases_to_u(const void *affine, size_t n, void *out_u, hipStream_t s);

@@ -1,9 +1,14 @@
 // msm_reduce.hip -- Pippenger bucket combination and the log-depth weighted bucket reduction (own TU).
 // Every array between the bucket kernel and the last kernel of the reduction holds XYZZ points in the internal 29-bit-limb
 // form (g1u.cuh, 256 B per point): no conversion per product, which is what the late, single-lane levels are made of.
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
 #include "context.h"
 #include "msm_kernels.cuh"
 #include "g1u.cuh"
+#include "msm_bits.cuh"
 
 namespace zk {
 
@@ -197,6 +202,15 @@ int launch_msm_gather_cd(const void *A, const void *B, unsigned nwin, unsigned c
 }
 int launch_msm_two_stage_out(const void *X, const void *Y, unsigned nwin, unsigned mbits, void *out, hipStream_t s) {
     msm_two_stage_out_kernel<<<(12 * nwin + 63) / 64, 64, 0, s>>>(X, Y, nwin, mbits, out);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+// the weighted sums of `narrays` arrays of 2^mbits entries by bits (mbits <= 8: a workgroup per (array, bit) holds its 2^(mbits-1) entries in
+// at most two rounds of 64 quads); S: narrays x (mbits + 1) points of scratch
+int launch_msm_weighted_bits(void *X, void *Y, unsigned narrays, unsigned mbits, void *S, hipStream_t s) {
+    if (mbits < 1 || mbits > 8) return ZK_E_ARG;
+    msm_bit_sums_kernel<true><<<dim3(narrays, mbits + 1), 4 * kBitQuads, 0, s>>>(X, mbits, S);
+    msm_bit_combine_kernel<3><<<narrays, 64, 0, s>>>(S, mbits, X, Y);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }

@@ -341,9 +341,16 @@ int msm_core(const void *d_scalars, const void *d_bases, size_t n_sub, unsigned 
         ZK_TRY(X.alloc(small_bytes));
         ZK_TRY(Y.alloc(small_bytes));
         ZK_TRY(out3.alloc(3 * (size_t)nwin * sizeof(G1Xyzz)));
-        ZK_HIP(hipMemsetAsync(Y.p, 0, small_bytes, cur_stream()));
         ZK_TRY(launch_msm_gather_cd(A.p, R.p, nwin, cm1, k, mbits, X.p, cur_stream()));
-        ZK_TRY(launch_msm_weighted_tail(X.p, Y.p, 2 * nwin, mbits, cur_stream()));   // 2 nwin problems of 2^mbits entries, 0-based weights
+        static const bool by_levels = [] { const char *e = getenv("ZK_MSM_WEIGHTED_LEVELS"); return e && e[0] == '1'; }();   // measurement: the r3 form
+        if (mbits <= 8 && !by_levels) {                     // by the bits of the weight: one addition per tree level (msm_reduce.hip)
+            DevBuf S;
+            ZK_TRY(S.alloc((size_t)2 * nwin * (mbits + 1) * kXyzzUBytes));
+            ZK_TRY(launch_msm_weighted_bits(X.p, Y.p, 2 * nwin, mbits, S.p, cur_stream()));
+        } else {
+            ZK_HIP(hipMemsetAsync(Y.p, 0, small_bytes, cur_stream()));
+            ZK_TRY(launch_msm_weighted_tail(X.p, Y.p, 2 * nwin, mbits, cur_stream()));   // 2 nwin problems of 2^mbits entries, 0-based weights
+        }
         ZK_TRY(launch_msm_two_stage_out(X.p, Y.p, nwin, mbits, out3.p, cur_stream()));
         std::vector<G1Xyzz> o(3 * (size_t)nwin);
         ZK_HIP(hipMemcpyAsync(o.data(), out3.p, o.size() * sizeof(G1Xyzz), hipMemcpyDeviceToHost, cur_stream()));
