@@ -1,8 +1,8 @@
 """Worker bodies for the world_size-2 tests of the multi-GPU host logic (spawned by torch.multiprocessing).
 
 `engine="oracle"` runs the per-shard compute on the CPU oracle (a TEST DOUBLE for the HIP engine, so the
-sharding / exchange / transcript logic is covered where there is no GPU); `engine="gpu"` uses the product's
-GpuShard (HIP kernels) with both ranks on cuda:0.  The process group is gloo in both cases; on a real
+sharding / exchange / transcript logic is covered where there is no GPU); `engine="gpu"` uses the HIP-backed
+adapters of tests/_sharded_protocol_model.py for the host-driven flow AND the product's one-call C-ABI provers, both ranks on cuda:0.  The process group is gloo in both cases; on a real
 multi-GPU node bench.py uses "nccl" (= RCCL)."""
 import os
 import sys
@@ -15,7 +15,7 @@ if ROOT not in sys.path:
 
 
 class OracleShard:
-    """test double of zkmle_amd.sharded.GpuShard on the CPU oracle"""
+    """test double of _sharded_protocol_model.HipShard on the CPU oracle"""
 
     def __init__(self, field, arr):
         self.field, self.arr = field, np.ascontiguousarray(arr, np.uint64)
@@ -82,27 +82,28 @@ def run(rank, world, port, engine, field, table, sum_tables, claimed, scalars, p
         import __graft_entry__ as G
         zk = G.import_package()
         S = zk.sharded
+        import _sharded_protocol_model as M
         comm = S.Comm()
         if engine == "gpu":
             from zkmle_amd import _lib
             _lib.check(zk.lib().zk_init(0))
-            mk = lambda a: S.GpuShard.from_array(field, a)
-            mk_sum = lambda a: S.GpuSumShard(field, [[zk.MultilinearPolynomial(field, t) for t in prod] for prod in a])
+            mk = lambda a: M.HipShard.from_array(field, a)
+            mk_sum = lambda a: M.HipSumShard(field, [[zk.MultilinearPolynomial(field, t) for t in prod] for prod in a])
         else:
             mk = lambda a: OracleShard(field, a)
             mk_sum = lambda a: OracleSumShard(field, a)
         res = {}
-        cs, rp, ch = S.sumcheck_basic_prove(comm, mk(S.shard_of(table, rank, world)))
+        cs, rp, ch = M.sumcheck_basic_prove(comm, mk(S.shard_of(table, rank, world)))
         res.update(basic_claimed=cs, basic_rounds=rp, basic_chal=ch)
         t = zk.Transcript()
         t.append(b"prefix")
-        co, gch = S.sumcheck_gkr_prove(comm, mk_sum(sum_tables[:, :, rank::world]), claimed, t)
+        co, gch = M.sumcheck_gkr_prove(comm, mk_sum(sum_tables[:, :, rank::world]), claimed, t)
         res.update(gkr_coeffs=co, gkr_chal=gch, gkr_tail=np.frombuffer(t.sample_random_challenge(), np.uint8))
         # the whole-table absorb alone (prover.rs:38-39): rank 0 hashes a streamed gather, the others get the 208-byte sponge
         tb = mk(S.shard_of(table, rank, world)).to_bytes()
         t = zk.Transcript()
         rx0 = comm.bytes_received
-        S.absorb_sharded_table(comm, t, tb, 8 * zk.limbs(field), chunk_elems=3)
+        M.absorb_sharded_table(comm, t, tb, 8 * zk.limbs(field), chunk_elems=3)
         res.update(absorb_rx=np.array([comm.bytes_received - rx0]), absorb_digest=np.frombuffer(t.sample_random_challenge(), np.uint8))
         if engine == "gpu":        # the product path: the same proofs through the C-ABI provers (zk_sharded_*), gloo as exchange callbacks
             shard = mk(S.shard_of(table, rank, world))
@@ -129,7 +130,7 @@ def run(rank, world, port, engine, field, table, sum_tables, claimed, scalars, p
             else:
                 from oracle import oracle as O
                 local = lambda: O.kzg_commit(scalars[lo:hi], points[lo:hi])
-            res["msm"] = S.msm(comm, local)
+            res["msm"] = M.msm(comm, local)
             if engine == "gpu":
                 res["dev_msm"] = S.msm_device(comm, zk.MultilinearPolynomial.vector(0, scalars[lo:hi]), zk.G1Bases(points[lo:hi]))
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)

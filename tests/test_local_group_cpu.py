@@ -1,5 +1,5 @@
 """CPU: the ranks-as-threads transport (include/zkmle.h zk_comm_local_group_*, zk_comm_host_exchange) and BASELINE config 5's
-8-way split of the host logic over it.  The per-shard compute is the oracle-backed test double of tests/_sharded_workers.py
+8-way split of the host-driven protocol model (tests/_sharded_protocol_model.py) over it.  The per-shard compute is the oracle-backed test double of tests/_sharded_workers.py
 (no GPU here); tests/test_gpu_config5_8way.py runs the same split through the C-ABI provers on HIP kernels."""
 import threading
 
@@ -9,6 +9,7 @@ import pytest
 import __graft_entry__ as G
 from oracle import oracle as O
 
+import _sharded_protocol_model as M
 from _sharded_workers import OracleShard, OracleSumShard
 from test_sharded_cpu import expected, rand_table
 
@@ -94,11 +95,11 @@ def test_config5_split_eight_ranks_host_flow(logn):
 
     def body(rank, comm):
         res = {}
-        cs, rp, ch = S.sumcheck_basic_prove(comm, OracleShard(field, S.shard_of(table, rank, world)))
+        cs, rp, ch = M.sumcheck_basic_prove(comm, OracleShard(field, S.shard_of(table, rank, world)))
         res.update(basic_claimed=cs, basic_rounds=rp, basic_chal=ch)
         t = zk.Transcript()
         t.append(b"prefix")
-        co, gch = S.sumcheck_gkr_prove(comm, OracleSumShard(field, sum_tables[:, :, rank::world]), claimed, t)
+        co, gch = M.sumcheck_gkr_prove(comm, OracleSumShard(field, sum_tables[:, :, rank::world]), claimed, t)
         res.update(gkr_coeffs=co, gkr_chal=gch, gkr_tail=np.frombuffer(t.sample_random_challenge(), np.uint8))
         return res
 

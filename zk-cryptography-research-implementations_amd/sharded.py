@@ -9,14 +9,12 @@ tests.  Every rank combines the gathered partial sums and runs the same transcri
 broadcast is needed.  The last k rounds run on the gathered G-element table.
 The MSM shards by slices: one Pippenger per rank, one all-gather of G affine points, G - 1 additions.
 
-Two layers:
-  * the product path -- `*_prove_device`, `mle_evaluate`, `msm`: ONE call each into the C ABI (include/zkmle.h
-    `zk_sharded_*`, csrc/zkmle_sharded.hip), where the rounds, the RCCL all-reduce of the limb sums and the transcript
-    kernel are enqueued back to back on the prover's stream; `Comm.native()` hands the library its communicator
-    (an RCCL communicator of its own when the process group is "nccl", exchange callbacks over the group otherwise);
-  * the host-driven reference flow of the same protocol (`sumcheck_basic_prove`, `sumcheck_gkr_prove`: one all-gather
-    per round from Python, per-shard compute through an `engine`), kept because it runs with a CPU test double where
-    there is no GPU (tests/test_sharded_cpu.py) and documents the exchange step by step.
+This module is the ctypes face of that: `*_prove_device`, `mle_evaluate`, `msm_device`, `kzg_open_device` are ONE call each into
+the C ABI (include/zkmle.h `zk_sharded_*`, csrc/zkmle_sharded.hip), where the rounds, the RCCL all-reduce of the limb sums and the
+transcript kernel are enqueued back to back on the prover's stream; `Comm.native()` hands the library its communicator (an RCCL
+communicator of its own when the process group is "nccl", exchange callbacks over the group otherwise), `LocalGroup` runs the ranks as
+threads of one process.  (A host-driven, exchange-by-exchange model of the same protocol lives with the tests:
+tests/_sharded_protocol_model.py.)
 """
 import ctypes as C
 
@@ -24,7 +22,6 @@ import numpy as np
 
 from . import _lib as L
 from .mle import MultilinearPolynomial, limbs
-from .sumcheck import Transcript, _decl as _sc_decl, lagrange_interpolate
 
 
 # ---- host field helpers (control path) ---------------------------------------------------------
@@ -32,23 +29,6 @@ def fe_add(field, a, b):
     out = np.zeros(limbs(field), np.uint64)
     L.check(L.lib().zk_fe_add(field, L.p64(np.ascontiguousarray(a, np.uint64)), L.p64(np.ascontiguousarray(b, np.uint64)), L.p64(out)))
     return out
-
-
-def fe_sum(field, rows):
-    acc = np.zeros(limbs(field), np.uint64)
-    for r in rows:
-        acc = fe_add(field, acc, r)
-    return acc
-
-
-def fe_to_bytes_be(field, a):
-    out = np.zeros(8 * limbs(field), np.uint8)
-    L.check(L.lib().zk_fe_to_bytes_be(field, L.p64(np.ascontiguousarray(a, np.uint64)), L.p8(out)))
-    return out.tobytes()
-
-
-def fe_to_bytes_le(field, a):
-    return fe_to_bytes_be(field, a)[::-1]
 
 
 class HostOps(C.Structure):
@@ -380,9 +360,9 @@ class LocalComm:
         self._native = None
 
 
-# ---- per-shard engines -----------------------------------------------------------------------------
+# ---- one rank's tables -------------------------------------------------------------------------------
 class GpuShard:
-    """one rank's local table in HBM; every method launches HIP kernels through the C ABI"""
+    """one rank's local table in HBM (the low-bit shard of the global table)"""
 
     def __init__(self, poly):
         self.poly = poly
@@ -392,104 +372,10 @@ class GpuShard:
     def from_array(cls, field, arr):
         return cls(MultilinearPolynomial(field, arr))
 
-    def spawn(self, arr):
-        return GpuShard.from_array(self.field, arr)
-
     def __len__(self):
         return len(self.poly)
 
-    def half_sums(self):
-        return self.poly.half_sums()
 
-    def fold_half_sums(self, r):
-        out, sums = self.poly.fold_half_sums(r)
-        return GpuShard(out), sums
-
-    def fold(self, r):
-        return GpuShard(MultilinearPolynomial.partial_evaluate(self.poly, 0, r))
-
-    def download(self):
-        return self.poly.evaluated_values
-
-    def to_bytes(self):
-        return self.poly.convert_to_bytes()
-
-
-def shard_of(global_table, rank, world):
-    """the low-bit shard of a host table: elements rank, rank + world, ..."""
-    return np.ascontiguousarray(np.asarray(global_table)[rank::world])
-
-
-def absorb_sharded_table(comm, t, local_bytes, esz, chunk_elems=1 << 15):
-    """transcript.append(convert_to_bytes(table)) (prover.rs:38-39) for a low-bit-sharded table: the sponge is sequential,
-    so rank 0 alone hashes -- the ranks send their canonical bytes to rank 0 chunk by chunk (gather), rank 0 interleaves a
-    chunk into global index order (element j of rank r is global j * G + r) and absorbs it, and the 208-byte sponge state
-    is broadcast.  Non-root ranks receive 208 bytes."""
-    G = comm.world
-    n = len(local_bytes) // esz
-    for off in range(0, n, chunk_elems):
-        parts = comm.gather_bytes(local_bytes[off * esz:(off + chunk_elems) * esz], 0)
-        if parts is not None:
-            views = [np.frombuffer(p, np.uint8).reshape(-1, esz) for p in parts]
-            t.append(np.stack(views, axis=1).tobytes())
-    if G > 1:
-        t.import_state(comm.broadcast_u64(t.export_state(), 0))
-
-
-# ---- sharded basic sumcheck (prover.rs:35-71) -------------------------------------------------------
-def sumcheck_basic_prove(comm, shard, absorb_table=True):
-    """-> (claimed_sum, round_polys (n, 2, limbs), challenges (n, limbs)); identical on every rank and
-    identical to the single-device proof of the interleaved global table."""
-    _declare_host()
-    field = shard.field
-    G = comm.world
-    assert G & (G - 1) == 0, "world size must be a power of two"
-    t = Transcript()
-    esz = 8 * limbs(field)
-    if absorb_table:
-        absorb_sharded_table(comm, t, shard.to_bytes(), esz)
-    rounds, chal = [], []
-    cur = shard
-    replicated = False
-
-    def global_half_sums(engine):
-        if replicated:
-            return engine.half_sums()
-        return combine(comm.all_gather(engine.half_sums()))
-
-    def combine(g):
-        return np.stack([fe_sum(field, g[:, 0]), fe_sum(field, g[:, 1])])
-
-    if len(cur) == 1:                                           # fewer local rounds than ranks: go replicated at once
-        cur = cur.spawn(comm.all_gather(cur.download()).reshape(G, -1))
-        replicated = True
-    total_len = len(shard) * G
-    if total_len == 1:
-        claimed = cur.download()[0]
-        t.append(fe_to_bytes_be(field, claimed))
-        return claimed, np.zeros((0, 2, limbs(field)), np.uint64), np.zeros((0, limbs(field)), np.uint64)
-    sums = global_half_sums(cur)
-    claimed = fe_add(field, sums[0], sums[1])                   # prover.rs:28
-    t.append(fe_to_bytes_be(field, claimed))                    # :40-41
-    nvars = total_len.bit_length() - 1
-    for _ in range(nvars):                                      # :46
-        rounds.append(sums.copy())
-        t.append(fe_to_bytes_be(field, sums[0]) + fe_to_bytes_be(field, sums[1]))    # :52-55
-        r = t.random_challenge_as_field_element(field)          # :58
-        chal.append(r)
-        if len(cur) >= 4:                                       # :61-63 fused with the next round's sums
-            cur, local = cur.fold_half_sums(r)
-            sums = local if replicated else combine(comm.all_gather(local))
-        elif len(cur) == 2:
-            cur = cur.fold(r)
-            if not replicated and G > 1:                        # one element per rank left: gather and continue replicated
-                cur = cur.spawn(comm.all_gather(cur.download()).reshape(G, -1))
-                replicated = True
-                sums = cur.half_sums()
-    return claimed, np.stack(rounds), np.stack(chal)
-
-
-# ---- sharded GKR sumcheck (sumcheck_gkr_protocol.rs:24-67) -------------------------------------------
 class GpuSumShard:
     """one rank's shards of the nprod x nfac tables of a SumPolynomial"""
 
@@ -498,101 +384,13 @@ class GpuSumShard:
         self.tables = tables          # list of lists of MultilinearPolynomial
         self.nprod, self.nfac = len(tables), len(tables[0])
 
-    def spawn(self, arrays):
-        return GpuSumShard(self.field, [[MultilinearPolynomial(self.field, a) for a in prod] for prod in arrays])
-
     def __len__(self):
         return len(self.tables[0][0])
 
-    def _arr(self, tabs):
-        flat = [p._h for prod in tabs for p in prod]
-        return (C.c_void_p * len(flat))(*flat)
 
-    def round_evals(self):
-        out = np.zeros((self.nfac + 1, limbs(self.field)), np.uint64)
-        L.check(_sc_decl().zk_sumpoly_round_evals(self._arr(self.tables), self.nprod, self.nfac, L.p64(out)))
-        return out
-
-    def fold_round_evals(self, r):
-        lib = _declare_host()
-        half = len(self) // 2
-        outs = [[MultilinearPolynomial.alloc(self.field, half) for _ in prod] for prod in self.tables]
-        ev = np.zeros((self.nfac + 1, limbs(self.field)), np.uint64)
-        L.check(lib.zk_sumpoly_fold_round_evals(self._arr(self.tables), self._arr(outs), self.nprod, self.nfac,
-                                                L.p64(np.ascontiguousarray(r, np.uint64)), L.p64(ev)))
-        return GpuSumShard(self.field, outs), ev
-
-    def fold(self, r):
-        return GpuSumShard(self.field, [[MultilinearPolynomial.partial_evaluate(p, 0, r) for p in prod] for prod in self.tables])
-
-    def download(self):
-        return np.stack([np.stack([p.evaluated_values for p in prod]) for prod in self.tables])
-
-
-def sumcheck_gkr_prove(comm, shard, claimed_sum, transcript):
-    """-> (round coefficient rows (n, nfac+1, limbs), challenges (n, limbs)); same bytes as the single-device prover"""
-    _declare_host()
-    field = shard.field
-    G = comm.world
-    npts = shard.nfac + 1
-    xs = np.stack([_from_u64(field, i) for i in range(npts)])
-    transcript.append(fe_to_bytes_be(field, claimed_sum))        # :35
-    total_len = len(shard) * G
-    nvars = total_len.bit_length() - 1
-    cur, replicated = shard, False
-
-    def combine(g):
-        return np.stack([fe_sum(field, g[:, k]) for k in range(npts)])
-
-    def gather_tables(engine):
-        g = comm.all_gather(engine.download())                   # (G, nprod, nfac, 1, limbs)
-        return np.ascontiguousarray(np.transpose(g[:, :, :, 0, :], (1, 2, 0, 3)))
-
-    if nvars == 0:
-        return np.zeros((0, npts, limbs(field)), np.uint64), np.zeros((0, limbs(field)), np.uint64)
-    if len(cur) == 1:
-        cur = cur.spawn(gather_tables(cur))
-        replicated = True
-    evals = cur.round_evals() if replicated else combine(comm.all_gather(cur.round_evals()))
-    coeffs, chal = [], []
-    for _ in range(nvars):                                       # :37
-        co = lagrange_interpolate(field, xs, evals)              # :49-50
-        transcript.append(b"".join(fe_to_bytes_le(field, c) for c in co))   # :52
-        coeffs.append(co)
-        r = transcript.random_challenge_as_field_element(field)  # :55
-        chal.append(r)
-        if len(cur) >= 4:
-            cur, local = cur.fold_round_evals(r)                 # :57 fused with the next :41
-            evals = local if replicated else combine(comm.all_gather(local))
-        elif len(cur) == 2:
-            cur = cur.fold(r)
-            if not replicated and G > 1:
-                cur = cur.spawn(gather_tables(cur))
-                replicated = True
-                evals = cur.round_evals()
-    return np.stack(coeffs), np.stack(chal)
-
-
-def _from_u64(field, v):
-    out = np.zeros(limbs(field), np.uint64)
-    L.check(L.lib().zk_fe_from_u64(field, v, L.p64(out)))
-    return out
-
-
-# ---- sharded MSM / commit (multilinear_kzg.rs:37-42) --------------------------------------------------
-def g1_sum(points):
-    lib = _declare_host()
-    acc = np.zeros(12, np.uint64)
-    for p in points:
-        out = np.zeros(12, np.uint64)
-        L.check(lib.zk_g1_add(L.p64(acc), L.p64(np.ascontiguousarray(p, np.uint64)), L.p64(out)))
-        acc = out
-    return acc
-
-
-def msm(comm, local_msm):
-    """local_msm: () -> this rank's partial point (12 limbs).  One all-gather of G points, G - 1 additions."""
-    return g1_sum(comm.all_gather(local_msm()))
+def shard_of(global_table, rank, world):
+    """the low-bit shard of a host table: elements rank, rank + world, ..."""
+    return np.ascontiguousarray(np.asarray(global_table)[rank::world])
 
 
 # ---- the product path: one C-ABI call per prover (include/zkmle.h zk_sharded_*, csrc/zkmle_sharded.hip) -------------------
