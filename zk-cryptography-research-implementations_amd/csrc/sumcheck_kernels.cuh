@@ -311,9 +311,6 @@ __device__ __forceinline__ void write_partials(Wide<F> (&acc)[NFAC + 1], Wide<F>
 
 // tables of `2 * half` entries; partials[t * gridDim.x + block]
 template <class F, int NFAC, bool SKIP1 = false>
-#ifdef ZK_RE_WAVES
-__attribute__((amdgpu_waves_per_eu(ZK_RE_WAVES, ZK_RE_WAVES)))
-#endif
 __global__ void __launch_bounds__(kBlock) round_evals_kernel(SumPolyTables tabs, int nprod, size_t half, void *__restrict__ partials, RoundFin fin) {
     if constexpr (NFAC == 2 && LazyProducts<F>::value) {
         __shared__ ProdWide<F> shp[3 * kBlock / 64];
