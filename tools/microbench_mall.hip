@@ -18,6 +18,34 @@ template <int STORE> __global__ void __launch_bounds__(256) fold_shape(const uin
     if (STORE) { out[2 * i] = x4(al, bl); out[2 * i + 1] = x4(ah, bh); }
     else { const uint4 v = x4(x4(al, bl), x4(ah, bh)); if (v.x == 0x12345678u && v.y == 0x9abcdef0u) out[0] = v; }
 }
+// the fold's shape with non-temporal stores (NT & 1) and loads (NT & 2): every byte is touched once per launch
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+template <int NT> __device__ __forceinline__ uint4 ldn(const uint4 *p) {
+    if (!(NT & 2)) return *p;
+    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <int NT> __device__ __forceinline__ void stn(uint4 *p, uint4 v) {
+    if (NT & 1) { v4u w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<v4u *>(p)); } else *p = v;
+}
+template <int NT> __global__ void __launch_bounds__(256) fold_shape_nt(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t half) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const uint4 al = ldn<NT>(in + 2 * i), ah = ldn<NT>(in + 2 * i + 1), bl = ldn<NT>(in + 2 * (i + half)), bh = ldn<NT>(in + 2 * (i + half) + 1);
+    stn<NT>(out + 2 * i, x4(al, bl));
+    stn<NT>(out + 2 * i + 1, x4(ah, bh));
+}
+template <int NT> static float time_nt(const uint4 *in, uint4 *out, size_t half, unsigned grid, int reps, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    for (int w = 0; w < 20; w++) hipLaunchKernelGGL(fold_shape_nt<NT>, dim3(grid), dim3(256), 0, s, in, out, half);
+    hipStreamSynchronize(s);
+    hipEventRecord(e0, s);
+    for (int w = 0; w < reps; w++) hipLaunchKernelGGL(fold_shape_nt<NT>, dim3(grid), dim3(256), 0, s, in, out, half);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f / reps;
+}
 int main(int argc, char **argv) {
     const int log_n = argc > 1 ? atoi(argv[1]) : 24, reps = argc > 2 ? atoi(argv[2]) : 40;
     if (log_n < 12 || log_n > 26) { fprintf(stderr, "log_n in 12 .. 26\n"); return 2; }
@@ -55,6 +83,14 @@ int main(int argc, char **argv) {
             printf("{\"log_n\": %d, \"shape\": \"%s\", \"order\": \"%s\", \"us\": %.2f, \"TBps\": %.3f}\n", log_n, store ? "fold (2 reads + 1 write)" : "read only",
                    mode ? "alternating" : "forwards", us, bytes / us * 1e-6);
         }
+    for (int rep = 0; rep < 2; rep++) {
+        const float t[4] = {time_nt<0>(in, out, half, grid, reps, s, e0, e1), time_nt<1>(in, out, half, grid, reps, s, e0, e1),
+                            time_nt<2>(in, out, half, grid, reps, s, e0, e1), time_nt<3>(in, out, half, grid, reps, s, e0, e1)};
+        const char *nm[4] = {"plain", "nt stores", "nt loads", "nt loads + stores"};
+        for (int k = 0; k < 4; k++)
+            printf("{\"log_n\": %d, \"shape\": \"fold (2 reads + 1 write), forwards\", \"policy\": \"%s\", \"us\": %.2f, \"TBps\": %.3f}\n", log_n, nm[k], t[k],
+                   ((double)n * 32 + (double)half * 32) / t[k] * 1e-6);
+    }
     CK(hipFree(in));
     CK(hipFree(out));
     return 0;
