@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
+#include <unistd.h>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 #include "../zk-cryptography-research-implementations_amd/csrc/dev_transcript.cuh"
 using namespace zk;
@@ -92,8 +94,13 @@ int main(int argc, char **argv) {
     if ((size_t)grid * kBlock > q) grid = (int)(q / kBlock > 0 ? q / kBlock : 1);
     SumPolyTables tabs{}, rtabs{};
     void *in[4], *out[4], *rout[4], *part, *rpart;
+    const int layout = argc > 5 ? atoi(argv[5]) : 0;           // 1: the four inputs allocated one after the other (as a caller's four tables are); 2: one slab, n * 32 B apart
+    char *slab = nullptr;
+    if (layout == 2) CK(hipMalloc(&slab, 4 * n * 32));
+    if (layout) for (int k = 0; k < 4; k++) { if (layout == 2) in[k] = slab + (size_t)k * n * 32; else CK(hipMalloc(&in[k], n * 32)); }
     for (int k = 0; k < 4; k++) {
-        CK(hipMalloc(&in[k], n * 32)); CK(hipMalloc(&out[k], half * 32)); CK(hipMalloc(&rout[k], half * 32));
+        if (!layout) CK(hipMalloc(&in[k], n * 32));
+        CK(hipMalloc(&out[k], half * 32)); CK(hipMalloc(&rout[k], half * 32));
         fill_random_kernel<F><<<4096, kBlock>>>(in[k], n, 0x5EED0900 + k, 0);
         // edge values where they hurt: the first entries of every stream are p - 1, the next ones 0
         std::vector<Fe<F>> edge(64);
@@ -175,9 +182,24 @@ int main(int argc, char **argv) {
             if (!fe_eq<F>(host_sum(hp, (size_t)t * grid, grid), host_sum(hr, (size_t)t * grid, grid))) { ok = 0; printf("  evaluation %d differs\n", t); }
         }
         const double bytes = (double)ntab * n * 32;
-        printf("{\"kernel\": \"round_evals<2, %s>\", \"log_n\": %d, \"ntab\": %d, \"grid\": %d, \"us\": %.2f, \"GBps\": %.1f, \"frac_hbm\": %.3f, \"matches_reference\": %s}\n",
-               skip1 ? "SKIP1" : "all", lg, ntab, grid, us, bytes / us / 1e3, bytes / us / 1e3 / 8000, ok ? "true" : "false");
+        printf("{\"kernel\": \"round_evals<2, %s>\", \"layout\": %d, \"in0\": \"%p\", \"in1\": \"%p\", \"log_n\": %d, \"ntab\": %d, \"grid\": %d, \"us\": %.2f, \"GBps\": %.1f, \"frac_hbm\": %.3f, \"matches_reference\": %s}\n",
+               skip1 ? "SKIP1" : "all", layout, in[0], in[1], lg, ntab, grid, us, bytes / us / 1e3, bytes / us / 1e3 / 8000, ok ? "true" : "false");
         bad += !ok;
+    }
+    // ---- the same first round launched on an IDLE chip: what the first kernel of a proof sees (the launches above run back to back) ----
+    for (int idle_us : {0, 50, 200, 1000}) {
+        std::vector<float> t;
+        for (int i = 0; i < 15; i++) {
+            CK(hipDeviceSynchronize());
+            if (idle_us) usleep(idle_us);
+            (void)hipEventRecord(e0);
+            round_evals_kernel<F, 2, false><<<grid, kBlock>>>(tabs, 2, half, part, RoundFin{});
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+            t.push_back(ms * 1000);
+        }
+        std::sort(t.begin(), t.end());
+        printf("{\"kernel\": \"round_evals<2, all>, one launch after the chip sat idle\", \"idle_us\": %d, \"us_median\": %.2f, \"us_min\": %.2f, \"us_max\": %.2f}\n", idle_us, t[t.size() / 2], t.front(), t.back());
     }
     return bad ? 1 : 0;
 }

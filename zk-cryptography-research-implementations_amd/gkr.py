@@ -346,6 +346,12 @@ def sparse_wiring_eval(field, gate_rows, out_bits, in_bits, pa, rb, rc, alpha=No
     return a, m
 
 
+def _fe_to_bytes_be(field, a):
+    out = np.zeros(8 * limbs(field), np.uint8)
+    L.check(L.lib().zk_fe_to_bytes_be(field, L.p64(np.ascontiguousarray(a, np.uint64)), L.p8(out)))
+    return out.tobytes()
+
+
 def sparse_verify(field, layer_gate_rows, out_bits, proof, inputs):
     """The verifier of gkr_protocol.rs:146-236 for the sparse representation (the wiring predicates are
     evaluated from the gate lists in O(#gates) on the GPU).  Used by tests and the config-4 bench."""
@@ -388,9 +394,9 @@ def sparse_verify(field, layer_gate_rows, out_bits, proof, inputs):
         expect = S.fe_add(field, mul(add_r, S.fe_add(field, wb, wc)), mul(mul_r, mul(wb, wc)))
         if not np.array_equal(expect, res.last_claimed_sum):
             return False
-        t.append(S.fe_to_bytes_be(field, wb))
+        t.append(_fe_to_bytes_be(field, wb))
         alpha = t.random_challenge_as_field_element(field)
-        t.append(S.fe_to_bytes_be(field, wc))
+        t.append(_fe_to_bytes_be(field, wc))
         beta = t.random_challenge_as_field_element(field)
         claim = S.fe_add(field, mul(alpha, wb), mul(beta, wc))
         pa, pb = ch[:k], ch[k:]
