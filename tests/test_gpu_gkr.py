@@ -83,9 +83,10 @@ def test_gkr_reference_roundtrips_and_derived(zk, ref_kats, derived_kats):
     check_against_oracle(zk, 0, k["layers"], k["inputs"])
 
 
-@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_gkr_random_circuits(zk, depth):
-    """random dense circuits of the reference's shape: layer i has 2^i gates reading 2^(i+1) wires"""
+    """random dense circuits of the reference's shape: layer i has 2^i gates reading 2^(i+1) wires.  Depth 8 is bench.py's `paths.gkr_dense` shape:
+    the last layer's add_i / mul_i have 2^23 entries and its alpha / beta combination folds 7 variables in one pass (fold_alpha_beta_kernel)"""
     rng = random.Random(depth)
     f = 0
     p = O.modulus(f)

@@ -106,4 +106,6 @@ int kzg_key_total(const zk_kzg_opening_key *k, const zk_g1_bases *g1, uint64_t *
 int pinned_pair(size_t bytes, void *out[2]);
 // a temporary table backed by the caching pool (internal provers: dozens of same-sized temporaries per proof)
 int table_alloc_pooled(int field, size_t len, zk_table **out);
+// alpha fold(in, rb) + beta fold(in, rc) over the k <= 8 top variables in one pass (gkr/src/utils.rs:23-68; zkmle_core.hip)
+int mle_fold_alpha_beta(const zk_table *in, size_t k, const uint64_t *alpha, const uint64_t *beta, const uint64_t *rb, const uint64_t *rc, zk_table *out);
 }

@@ -514,6 +514,44 @@ template <class F, int K> __global__ void __launch_bounds__(kFoldSplitBlock) fol
     }
 }
 
+// compute_new_add_i_mul_i (gkr/src/utils.rs:23-68) in ONE pass: alpha fold(x, rb) + beta fold(x, rc), both chains folding the SAME k top variables of x, is
+// sum_h (alpha eq(rb, h) + beta eq(rc, h)) x[h n + j] -- the reference's 2 k partial evaluations, two scalar products and one addition read x 2 (2 - 2^-k)
+// times and launch 2 k + 3 kernels; this reads it once.  Field arithmetic is exact, so the entries are the same canonical elements.
+constexpr int kFoldABMax = 8;
+template <class F> struct FoldABArgs {
+    Fe<F> rb[kFoldABMax], rc[kFoldABMax], alpha, beta;
+    int k;
+};
+template <class F> __global__ void __launch_bounds__(kBlock) fold_alpha_beta_kernel(const void *__restrict__ in, void *__restrict__ out, size_t n, FoldABArgs<F> a) {
+    __shared__ Ufe<F> sw[1 << kFoldABMax];
+    const unsigned nw = 1u << a.k;
+    for (unsigned e = threadIdx.x; e < nw; e += blockDim.x) {
+        Fe<F> wb = a.alpha, wc = a.beta;
+        const Fe<F> one = fe_one<F>();
+#pragma unroll 1
+        for (int l = 0; l < a.k; l++) {                              // variable 0 = the most significant bit (evaluation_form.rs:61-106 with var 0, k times)
+            const bool bit = ((e >> (a.k - 1 - l)) & 1u) != 0;
+            wb = fe_mul<F>(wb, bit ? a.rb[l] : fe_sub<F>(one, a.rb[l]));
+            wc = fe_mul<F>(wc, bit ? a.rc[l] : fe_sub<F>(one, a.rc[l]));
+        }
+        sw[e] = u_reduce_once<F>(u_from_std<F>(fe_add<F>(wb, wc)));
+    }
+    __syncthreads();
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        RawAcc<F> ra;
+#pragma unroll
+        for (int c = 0; c < 2 * UParams<F>::L; c++) ra.c[c] = 0;
+#pragma unroll 1
+        for (unsigned i0 = 0; i0 < nw; i0 += 2) {                    // nw >= 2; two products between normalizations (kRawCarryEvery allows four)
+            const Fe<F> x0 = fe_load<F>(in, j + (size_t)i0 * n), x1 = fe_load<F>(in, j + (size_t)(i0 + 1) * n);
+            raw_mul_add<F>(ra, u_from_limbs32<F>(x0), sw[i0]);
+            raw_mul_add<F>(ra, u_from_limbs32<F>(x1), sw[i0 + 1]);
+            raw_normalize<F>(ra);
+        }
+        fe_store<F>(out, j, u_to_limbs32<F>(u_reduce_once<F>(raw_mont_reduce<F>(ra))));
+    }
+}
+
 // ---- element-wise and tensor operations --------------------------------------------------------------
 enum { OP_SCALAR_MUL = 0, OP_ADD = 1, OP_SUB_SCALAR = 2, OP_TO_CANONICAL_BE = 3, OP_HI_MINUS_LO = 4 };
 

@@ -219,6 +219,30 @@ template <class F> static Fe<F> load_host(const uint64_t *src) {
     return e;
 }
 
+// alpha fold(in, rb) + beta fold(in, rc), both folding the k top variables (gkr/src/utils.rs:23-68), in one pass (mle_kernels.cuh
+// fold_alpha_beta_kernel).  out: a table of in->len >> k entries.  Host values in, nothing uploaded: they travel as kernel arguments.
+int mle_fold_alpha_beta(const zk_table *in, size_t k, const uint64_t *alpha, const uint64_t *beta, const uint64_t *rb, const uint64_t *rc, zk_table *out) {
+    if (!in || !out || !alpha || !beta || !rb || !rc) return ZK_E_ARG;
+    if (k < 1 || k > (size_t)kFoldABMax) return ZK_E_RANGE;
+    if (!is_pow2(in->len) || (in->len >> k) == 0) return ZK_E_NOT_POW2;
+    const size_t n = in->len >> k;
+    if (out->field != in->field || out->len < n || out->dptr == in->dptr) return ZK_E_ARG;
+    ZK_TRY(require_device());
+    const int limbs = field_limbs64(in->field);
+    ZK_DISPATCH_FIELD(in->field, {
+        FoldABArgs<F> a{};
+        for (size_t l = 0; l < k; l++) { a.rb[l] = load_host<F>(rb + l * limbs); a.rc[l] = load_host<F>(rc + l * limbs); }
+        a.alpha = load_host<F>(alpha);
+        a.beta = load_host<F>(beta);
+        a.k = (int)k;
+        fold_alpha_beta_kernel<F><<<grid_for(n), kBlock, 0, cur_stream()>>>(in->dptr, out->dptr, n, a);
+    });
+    ZK_HIP(hipGetLastError());
+    out->len = n;
+    return ZK_OK;
+}
+
+
 }  // namespace zk
 
 using namespace zk;

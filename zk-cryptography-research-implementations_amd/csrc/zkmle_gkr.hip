@@ -79,6 +79,10 @@ int fold_chain(const zk_table *src, const uint64_t *vals, size_t k, int limbs, T
 int alpha_beta_fold(const zk_table *abc, const uint64_t *alpha, const uint64_t *beta, const uint64_t *rb, const uint64_t *rc,
                     size_t k, int limbs, TablePtr &out) {
     if (k == 0) return ZK_E_RANGE;                       // rb_values[0] :38
+    if (k <= 8 && (abc->len >> k) != 0) {                // both chains and the combination as one weighted fold (mle_kernels.cuh fold_alpha_beta_kernel)
+        ZK_TRY(alloc_table(abc->field, abc->len >> k, out));
+        return mle_fold_alpha_beta(abc, k, alpha, beta, rb, rc, out.get());
+    }
     TablePtr frb, frc;
     ZK_TRY(fold_chain(abc, rb, k, limbs, frb));
     ZK_TRY(fold_chain(abc, rc, k, limbs, frc));
@@ -121,16 +125,15 @@ template <class F> int add_mul_mle(const zk_gate *g, size_t ngates, size_t layer
         if (pos >= n) return ZK_E_RANGE;
         (g[k].op == 0 ? pa : pm).push_back(pos);
     }
-    for (int w = 0; w < 2; w++) {
-        std::vector<uint64_t> &pos = w ? pm : pa;
-        if (pos.empty()) continue;
-        void *dpos;
-        ZK_TRY(scratch(pos.size() * 8, &dpos));
-        ZK_HIP(zk::memcpy_on_stream(dpos, pos.data(), pos.size() * 8, hipMemcpyHostToDevice));
-        scatter_one_kernel<F><<<grid_for(pos.size()), kBlock, 0, cur_stream()>>>((w ? mul_i : add_i)->dptr, (const uint64_t *)dpos, pos.size());
-        ZK_HIP(hipGetLastError());
-        ZK_HIP(hipStreamSynchronize(cur_stream()));
-    }
+    if (ngates == 0) return ZK_OK;
+    const size_t na = pa.size();
+    pa.insert(pa.end(), pm.begin(), pm.end());                                         // one upload: the add positions, then the mul positions
+    void *dpos;
+    ZK_TRY(scratch(pa.size() * 8, &dpos));
+    ZK_HIP(zk::memcpy_on_stream(dpos, pa.data(), pa.size() * 8, hipMemcpyHostToDevice));   // returns when the copy has been made
+    if (na) scatter_one_kernel<F><<<grid_for(na), kBlock, 0, cur_stream()>>>(add_i->dptr, (const uint64_t *)dpos, na);
+    if (pa.size() > na) scatter_one_kernel<F><<<grid_for(pa.size() - na), kBlock, 0, cur_stream()>>>(mul_i->dptr, (const uint64_t *)dpos + na, pa.size() - na);
+    ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
 
