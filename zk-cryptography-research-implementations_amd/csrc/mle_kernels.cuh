@@ -522,33 +522,70 @@ template <class F> struct FoldABArgs {
     Fe<F> rb[kFoldABMax], rc[kFoldABMax], alpha, beta;
     int k;
 };
-template <class F> __global__ void __launch_bounds__(kBlock) fold_alpha_beta_kernel(const void *__restrict__ in, void *__restrict__ out, size_t n, FoldABArgs<F> a) {
-    __shared__ Ufe<F> sw[1 << kFoldABMax];
-    const unsigned nw = 1u << a.k;
-    for (unsigned e = threadIdx.x; e < nw; e += blockDim.x) {
-        Fe<F> wb = a.alpha, wc = a.beta;
-        const Fe<F> one = fe_one<F>();
+// `split` (a power of two, <= 2^k / 2 and <= kBlock / 16) lanes share an output: part q sums the inputs h = q 2^k / split ..., the parts meet in LDS (a short
+// output -- 2^16 entries from a 2^23-entry predicate -- is 256 workgroups of one lane per output, each lane a chain of 128 dependent loads: 136 us for 268 MB).
+// the 2^k weights alpha eq(rb, h) + beta eq(rc, h) in the scan's form, once per pass (2 k dependent products per weight: worked out in every workgroup
+// of a 4096-workgroup pass they were 100 of its 160 us)
+template <class F> __global__ void __launch_bounds__(1 << kFoldABMax) fold_alpha_beta_weights_kernel(FoldABArgs<F> a, Ufe<F> *__restrict__ w) {
+    const unsigned e = threadIdx.x;
+    if (e >= (1u << a.k)) return;
+    Fe<F> wb = a.alpha, wc = a.beta;
+    const Fe<F> one = fe_one<F>();
 #pragma unroll 1
-        for (int l = 0; l < a.k; l++) {                              // variable 0 = the most significant bit (evaluation_form.rs:61-106 with var 0, k times)
-            const bool bit = ((e >> (a.k - 1 - l)) & 1u) != 0;
-            wb = fe_mul<F>(wb, bit ? a.rb[l] : fe_sub<F>(one, a.rb[l]));
-            wc = fe_mul<F>(wc, bit ? a.rc[l] : fe_sub<F>(one, a.rc[l]));
-        }
-        sw[e] = u_reduce_once<F>(u_from_std<F>(fe_add<F>(wb, wc)));
+    for (int l = 0; l < a.k; l++) {                                  // variable 0 = the most significant bit (evaluation_form.rs:61-106 with var 0, k times)
+        const bool bit = ((e >> (a.k - 1 - l)) & 1u) != 0;
+        wb = fe_mul<F>(wb, bit ? a.rb[l] : fe_sub<F>(one, a.rb[l]));
+        wc = fe_mul<F>(wc, bit ? a.rc[l] : fe_sub<F>(one, a.rc[l]));
     }
+    w[e] = u_reduce_once<F>(u_from_std<F>(fe_add<F>(wb, wc)));
+}
+template <class F> __global__ void __launch_bounds__(kBlock) fold_alpha_beta_kernel(const void *__restrict__ in, void *__restrict__ out, size_t n, int k,
+                                                                                    const Ufe<F> *__restrict__ w, unsigned split) {
+    __shared__ Ufe<F> sw[1 << kFoldABMax];
+    __shared__ Fe<F> parts[kBlock];
+    const unsigned nw = 1u << k;
+    for (unsigned e = threadIdx.x; e < nw; e += blockDim.x) sw[e] = w[e];
     __syncthreads();
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
-        RawAcc<F> ra;
+    const unsigned kout = kBlock / split, per = nw / split;          // outputs per workgroup, inputs per lane (>= 2)
+    const unsigned q = threadIdx.x / kout, jj = threadIdx.x % kout;
+    const size_t nblk = (n + kout - 1) / kout;
+    for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {    // the same trip count for every lane of a workgroup
+        const size_t j = blk * kout + jj;
+        Fe<F> v = fe_zero<F>();
+        if (j < n) {
+            RawAcc<F> ra;
 #pragma unroll
-        for (int c = 0; c < 2 * UParams<F>::L; c++) ra.c[c] = 0;
+            for (int c = 0; c < 2 * UParams<F>::L; c++) ra.c[c] = 0;
+            unsigned i0 = q * per;
+            const unsigned i1 = i0 + per;
 #pragma unroll 1
-        for (unsigned i0 = 0; i0 < nw; i0 += 2) {                    // nw >= 2; two products between normalizations (kRawCarryEvery allows four)
-            const Fe<F> x0 = fe_load<F>(in, j + (size_t)i0 * n), x1 = fe_load<F>(in, j + (size_t)(i0 + 1) * n);
-            raw_mul_add<F>(ra, u_from_limbs32<F>(x0), sw[i0]);
-            raw_mul_add<F>(ra, u_from_limbs32<F>(x1), sw[i0 + 1]);
-            raw_normalize<F>(ra);
+            for (; i0 + 4 <= i1; i0 += 4) {                          // four products between normalizations (kRawCarryEvery)
+                Fe<F> x[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[i] = fe_load<F>(in, j + (size_t)(i0 + i) * n);
+#pragma unroll
+                for (int i = 0; i < 4; i++) raw_mul_add<F>(ra, u_from_limbs32<F>(x[i]), sw[i0 + i]);
+                raw_normalize<F>(ra);
+            }
+            if (i0 < i1) {                                           // per = 2
+                const Fe<F> x0 = fe_load<F>(in, j + (size_t)i0 * n), x1 = fe_load<F>(in, j + (size_t)(i0 + 1) * n);
+                raw_mul_add<F>(ra, u_from_limbs32<F>(x0), sw[i0]);
+                raw_mul_add<F>(ra, u_from_limbs32<F>(x1), sw[i0 + 1]);
+                raw_normalize<F>(ra);
+            }
+            v = u_to_limbs32<F>(u_reduce_once<F>(raw_mont_reduce<F>(ra)));
         }
-        fe_store<F>(out, j, u_to_limbs32<F>(u_reduce_once<F>(raw_mont_reduce<F>(ra))));
+        if (split == 1) {
+            if (j < n) fe_store<F>(out, j, v);
+            continue;
+        }
+        parts[threadIdx.x] = v;
+        __syncthreads();
+        if (q == 0 && j < n) {
+            for (unsigned s2 = 1; s2 < split; s2++) v = fe_add<F>(v, parts[s2 * kout + jj]);
+            fe_store<F>(out, j, v);
+        }
+        __syncthreads();
     }
 }
 

@@ -17,11 +17,6 @@ void set_last_error(const std::string &s) { g_last_error = s; }
 
 static thread_local hipStream_t g_stream = nullptr;
 hipStream_t cur_stream() { return g_stream; }
-hipError_t memcpy_on_stream(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, g_stream);
-    return e != hipSuccess ? e : hipStreamSynchronize(g_stream);
-}
-hipError_t memset_on_stream(void *dst, int value, size_t bytes) { return hipMemsetAsync(dst, value, bytes, g_stream); }
 hipError_t stream_wait_idle() {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -30,6 +25,14 @@ hipError_t stream_wait_idle() {
         if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 300.0) return hipStreamSynchronize(g_stream);
     }
 }
+// Small copies (a few field elements down, a list of positions up) wait by polling: a blocking hipStreamSynchronize wakes up 20-30 us after the copy has
+// landed, and a proof made of many small calls (the dense GKR prover: ~30 such copies) spent a third of its time there.  Large ones block at once.
+hipError_t memcpy_on_stream(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, g_stream);
+    if (e != hipSuccess) return e;
+    return bytes <= ((size_t)1 << 20) ? stream_wait_idle() : hipStreamSynchronize(g_stream);
+}
+hipError_t memset_on_stream(void *dst, int value, size_t bytes) { return hipMemsetAsync(dst, value, bytes, g_stream); }
 
 struct DeviceScratch {
     void *dev = nullptr;
@@ -235,7 +238,16 @@ int mle_fold_alpha_beta(const zk_table *in, size_t k, const uint64_t *alpha, con
         a.alpha = load_host<F>(alpha);
         a.beta = load_host<F>(beta);
         a.k = (int)k;
-        fold_alpha_beta_kernel<F><<<grid_for(n), kBlock, 0, cur_stream()>>>(in->dptr, out->dptr, n, a);
+        // lanes per output: enough lanes to fill the chip (2^20), at least two inputs per lane, at least 16 neighbouring outputs per part (512 contiguous bytes)
+        unsigned split = 1;
+        while ((n * split) < ((size_t)1 << 20) && split * 2 <= (1u << k) / 2 && split * 2 <= (unsigned)kBlock / 16) split *= 2;
+        const size_t nblk = (n + kBlock / split - 1) / (kBlock / split);
+        void *w = nullptr;
+        ZK_TRY(pool_alloc(sizeof(Ufe<F>) << k, &w));
+        fold_alpha_beta_weights_kernel<F><<<1, 1 << kFoldABMax, 0, cur_stream()>>>(a, (Ufe<F> *)w);
+        fold_alpha_beta_kernel<F><<<(unsigned)(nblk < (size_t)kMaxBlocks ? nblk : (size_t)kMaxBlocks), kBlock, 0, cur_stream()>>>(in->dptr, out->dptr, n, (int)k,
+                                                                                                                                (const Ufe<F> *)w, split);
+        pool_free(w);                                                // stream-ordered: this thread's next user of the block runs behind the kernel
     });
     ZK_HIP(hipGetLastError());
     out->len = n;

@@ -113,27 +113,67 @@ template <class F> int circuit_evaluate(const zk_gate *gates, const size_t *gate
     return circuit_evaluate_device(F::ID, gates, gate_counts, nlayers, ce.lsz.data(), inputs, ce.evals.data());
 }
 
-template <class F> int add_mul_mle(const zk_gate *g, size_t ngates, size_t layer_index, TablePtr &add_i, TablePtr &mul_i) {
+// positions of a layer's gates in its dense predicates (:139-155), appended to `pos`: the add gates' first, then the mul gates'
+int layer_positions(const zk_gate *g, size_t ngates, size_t layer_index, std::vector<uint64_t> &pos, size_t *na, size_t *nm) {
+    const size_t n = (size_t)1 << zk_num_of_layer_variables(layer_index);
+    std::vector<uint64_t> pm;
+    const size_t before = pos.size();
+    for (size_t k = 0; k < ngates; k++) {
+        size_t at = zk_wiring_index(layer_index, g[k].out, g[k].left, g[k].right);
+        if (at >= n) return ZK_E_RANGE;
+        (g[k].op == 0 ? pos : pm).push_back(at);
+    }
+    *na = pos.size() - before;
+    *nm = pm.size();
+    pos.insert(pos.end(), pm.begin(), pm.end());
+    return ZK_OK;
+}
+// add_i / mul_i from positions that are already on the device (na add positions, then nm mul positions): two fills and two scatters, nothing to wait for
+template <class F> int add_mul_mle_dev(const uint64_t *dpos, size_t na, size_t nm, size_t layer_index, TablePtr &add_i, TablePtr &mul_i) {
     size_t n = (size_t)1 << zk_num_of_layer_variables(layer_index);
     ZK_TRY(alloc_table(F::ID, n, add_i));
     ZK_TRY(alloc_table(F::ID, n, mul_i));
     ZK_HIP(hipMemsetAsync(add_i->dptr, 0, n * 4 * F::N, cur_stream()));                     // vec![F::zero(); 2^vars] :133-134
     ZK_HIP(hipMemsetAsync(mul_i->dptr, 0, n * 4 * F::N, cur_stream()));
-    std::vector<uint64_t> pa, pm;
-    for (size_t k = 0; k < ngates; k++) {
-        size_t pos = zk_wiring_index(layer_index, g[k].out, g[k].left, g[k].right);   // :139-155
-        if (pos >= n) return ZK_E_RANGE;
-        (g[k].op == 0 ? pa : pm).push_back(pos);
-    }
-    if (ngates == 0) return ZK_OK;
-    const size_t na = pa.size();
-    pa.insert(pa.end(), pm.begin(), pm.end());                                         // one upload: the add positions, then the mul positions
-    void *dpos;
-    ZK_TRY(scratch(pa.size() * 8, &dpos));
-    ZK_HIP(zk::memcpy_on_stream(dpos, pa.data(), pa.size() * 8, hipMemcpyHostToDevice));   // returns when the copy has been made
-    if (na) scatter_one_kernel<F><<<grid_for(na), kBlock, 0, cur_stream()>>>(add_i->dptr, (const uint64_t *)dpos, na);
-    if (pa.size() > na) scatter_one_kernel<F><<<grid_for(pa.size() - na), kBlock, 0, cur_stream()>>>(mul_i->dptr, (const uint64_t *)dpos + na, pa.size() - na);
+    if (na) scatter_one_kernel<F><<<grid_for(na), kBlock, 0, cur_stream()>>>(add_i->dptr, dpos, na);
+    if (nm) scatter_one_kernel<F><<<grid_for(nm), kBlock, 0, cur_stream()>>>(mul_i->dptr, dpos + na, nm);
     ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+template <class F> int add_mul_mle(const zk_gate *g, size_t ngates, size_t layer_index, TablePtr &add_i, TablePtr &mul_i) {
+    std::vector<uint64_t> pos;
+    size_t na = 0, nm = 0;
+    ZK_TRY(layer_positions(g, ngates, layer_index, pos, &na, &nm));
+    void *dpos = nullptr;
+    if (!pos.empty()) {
+        ZK_TRY(scratch(pos.size() * 8, &dpos));
+        ZK_HIP(zk::memcpy_on_stream(dpos, pos.data(), pos.size() * 8, hipMemcpyHostToDevice));   // returns when the copy has been made
+    }
+    return add_mul_mle_dev<F>((const uint64_t *)dpos, na, nm, layer_index, add_i, mul_i);
+}
+
+// what a proof uploads ONCE instead of once per layer: every layer's wiring positions and every layer's evaluations
+struct PoolBlock2 {
+    void *p = nullptr;
+    ~PoolBlock2() { pool_free(p); }
+    int alloc(size_t bytes) { return pool_alloc(bytes ? bytes : 8, &p); }
+};
+struct LayerPositions {
+    PoolBlock2 dev;
+    std::vector<size_t> off, na, nm;
+    const uint64_t *at(size_t L) const { return (const uint64_t *)dev.p + off[L]; }
+};
+int upload_positions(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, LayerPositions &lp) {
+    std::vector<uint64_t> pos;
+    lp.off.assign(nlayers, 0); lp.na.assign(nlayers, 0); lp.nm.assign(nlayers, 0);
+    size_t goff = 0;
+    for (size_t L = 0; L < nlayers; L++) {
+        lp.off[L] = pos.size();
+        ZK_TRY(layer_positions(gates + goff, gate_counts[L], L, pos, &lp.na[L], &lp.nm[L]));
+        goff += gate_counts[L];
+    }
+    ZK_TRY(lp.dev.alloc(pos.size() * 8));
+    if (!pos.empty()) ZK_HIP(zk::memcpy_on_stream(lp.dev.p, pos.data(), pos.size() * 8, hipMemcpyHostToDevice));
     return ZK_OK;
 }
 
@@ -149,10 +189,11 @@ int build_fbc(TablePtr &add_bc, TablePtr &mul_bc, const zk_table *w, TablePtr &a
 
 template <class F> int derive_bc(const zk_gate *layer_gates, size_t ngates, size_t L, const uint64_t *ra, const uint64_t *alpha,
                                  const uint64_t *beta, const uint64_t *rb, const uint64_t *rc, size_t nr, TablePtr &add_bc,
-                                 TablePtr &mul_bc) {
+                                 TablePtr &mul_bc, const LayerPositions *lp = nullptr) {
     const int limbs = F::N / 2;
     TablePtr add_abc, mul_abc;
-    ZK_TRY((add_mul_mle<F>(layer_gates, ngates, L, add_abc, mul_abc)));               // gkr_protocol.rs:58
+    if (lp) ZK_TRY((add_mul_mle_dev<F>(lp->at(L), lp->na[L], lp->nm[L], L, add_abc, mul_abc)));   // gkr_protocol.rs:58, positions uploaded with the other layers'
+    else ZK_TRY((add_mul_mle<F>(layer_gates, ngates, L, add_abc, mul_abc)));
     if (L == 0) {                                                                     // :60-72
         ZK_TRY(alloc_table(F::ID, add_abc->len / 2, add_bc));
         ZK_TRY(alloc_table(F::ID, mul_abc->len / 2, mul_bc));
@@ -186,11 +227,19 @@ template <class F> int gkr_prove(const zk_gate *gates, const size_t *gate_counts
     ZK_TRY(zk_mle_evaluate(w0t.get(), ra, 1, claim));                                // :51
     std::vector<uint64_t> rb, rc;
     size_t nr = 0, coff = 0, choff = 0;
+    // one upload each for what every layer needs from the host: the wiring positions and the layer evaluations (w_i are views into the block)
+    LayerPositions lp;
+    ZK_TRY(upload_positions(gates, gate_counts, nlayers, lp));
+    PoolBlock2 wdev;
+    ZK_TRY(wdev.alloc(ce.evals.size() * 8));
+    ZK_HIP(zk::memcpy_on_stream(wdev.p, ce.evals.data(), ce.evals.size() * 8, hipMemcpyHostToDevice));
     for (size_t L = 0; L < nlayers; L++) {                                           // :57
-        TablePtr add_bc, mul_bc, add_w, mul_w, w;
-        ZK_TRY((derive_bc<F>(gates + ce.goff[L], gate_counts[L], L, ra, alpha, beta, rb.data(), rc.data(), nr, add_bc, mul_bc)));
-        ZK_TRY(upload_table(F::ID, ce.evals.data() + ce.eoff[L + 1] * L64, ce.lsz[L + 1], w));   // :88-89 w_i_polynomial
-        ZK_TRY(build_fbc(add_bc, mul_bc, w.get(), add_w, mul_w));                    // :95
+        TablePtr add_bc, mul_bc, add_w, mul_w;
+        ZK_TRY((derive_bc<F>(gates + ce.goff[L], gate_counts[L], L, ra, alpha, beta, rb.data(), rc.data(), nr, add_bc, mul_bc, &lp)));
+        if (!is_pow2(ce.lsz[L + 1])) return ZK_E_NOT_POW2;                           // :88-89 w_i_polynomial: new() asserts a power of two
+        zk_table wview{F::ID, ce.lsz[L + 1], (char *)wdev.p + ce.eoff[L + 1] * L64 * 8, 0};
+        zk_table *const w_ptr = &wview;
+        ZK_TRY(build_fbc(add_bc, mul_bc, w_ptr, add_w, mul_w));                      // :95
         size_t bclen = add_bc->len, rounds = ilog2(bclen);
         memcpy(layer_claims + L * L64, claim, L64 * 8);
         const zk_table *tabs[4] = {add_bc.get(), add_w.get(), mul_bc.get(), mul_w.get()};
@@ -199,8 +248,8 @@ template <class F> int gkr_prove(const zk_gate *gates, const size_t *gate_counts
         if (L + 1 < nlayers) {                                                       // :109
             size_t mid = rounds / 2;                                                 // :120 / utils.rs:75
             uint64_t wbe[6], wce[6];
-            ZK_TRY(zk_mle_evaluate(w.get(), lch, mid, wbe));                         // utils.rs:78
-            ZK_TRY(zk_mle_evaluate(w.get(), lch + mid * L64, rounds - mid, wce));    // :79
+            ZK_TRY(zk_mle_evaluate(w_ptr, lch, mid, wbe));                           // utils.rs:78
+            ZK_TRY(zk_mle_evaluate(w_ptr, lch + mid * L64, rounds - mid, wce));      // :79
             memcpy(wb_evals + L * L64, wbe, L64 * 8);                                // :116-117
             memcpy(wc_evals + L * L64, wce, L64 * 8);
             rb.assign(lch, lch + mid * L64);                                         // :121-123
