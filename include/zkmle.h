@@ -280,7 +280,10 @@ int zk_circuit_add_mul_mle(int field, const zk_gate *layer_gates, size_t ngates,
 /* gkr_protocol::prove  gkr_protocol.rs:26-143.  Flattened Proof (:17-23):
  *   circuit_output[*output_len]; claimed_sum[1]; layer_claims[nlayers] (each layer's
  *   SumcheckProverProof.claimed_sum); coeffs: per layer rounds(L)*3 coefficients, rounds(L)=2(L+1);
- *   challenges: per layer rounds(L); wb_evals / wc_evals [nlayers-1]. */
+ *   challenges: per layer rounds(L); wb_evals / wc_evals [nlayers-1].
+ * A well-formed circuit (layer i writes wires 0 .. 2^i - 1, no gate twice) is proved from its gate lists (zk_gkr_sparse_*): the same transcript and
+ * the same proof bytes without the 2^(3 i + 2)-entry dense predicates; the gate lists of the calling thread's last circuit stay compiled on the device.
+ * ZK_GKR_DENSE_TABLES=1 (environment, read per call) keeps the reference's dense representation, which also serves every other shape. */
 size_t zk_gkr_rounds(size_t layer_index);
 int zk_gkr_prove(int field, const zk_gate *gates, const size_t *gate_counts, size_t nlayers,
                  const uint64_t *inputs, size_t ninputs, uint64_t *circuit_output, size_t *output_len,

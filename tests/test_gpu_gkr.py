@@ -100,6 +100,52 @@ def test_gkr_random_circuits(zk, depth):
     check_against_oracle(zk, f, spec, inputs)
 
 
+@pytest.mark.parametrize("depth", [1, 3, 5, 8])
+def test_gkr_random_circuits_on_the_dense_tables(zk, depth, monkeypatch):
+    """zk_gkr_prove proves a well-formed circuit from its gate lists; ZK_GKR_DENSE_TABLES=1 keeps the reference's dense add_i / mul_i representation
+    (the path that also serves repeated gates and the shapes the reference panics on): the same proof, against the oracle"""
+    monkeypatch.setenv("ZK_GKR_DENSE_TABLES", "1")
+    test_gkr_random_circuits(zk, depth)
+
+
+def test_gkr_both_representations_same_bytes(zk, monkeypatch):
+    rng = random.Random(77)
+    spec = []
+    for i in range(6):
+        n_out, n_in = (1 << i), (1 << (i + 1))
+        spec.append([[rng.randrange(n_in), rng.randrange(n_in), o, rng.choice(["add", "mul"])] for o in range(n_out)])
+    x = zk.from_ints(0, [rng.randrange(O.modulus(0)) for _ in range(1 << 6)])
+    circuit = mk_circuit(zk, 0, spec)
+    a = zk.gkr.prove(circuit, x)
+    a2 = zk.gkr.prove(circuit, x)                              # the compiled gate lists of the first call, reused
+    monkeypatch.setenv("ZK_GKR_DENSE_TABLES", "1")
+    b = zk.gkr.prove(circuit, x)
+    for p in (a2, b):
+        assert np.array_equal(a.circuit_output, p.circuit_output) and np.array_equal(a.claimed_sum, p.claimed_sum)
+        assert all(np.array_equal(u, v) for u, v in zip(a._flat, p._flat))
+        assert np.array_equal(a.wb_evaluations, p.wb_evaluations) and np.array_equal(a.wc_evaluations, p.wc_evaluations)
+    # a repeated gate is ONE entry of the dense predicate: such circuits stay with the dense tables whatever the switch says
+    monkeypatch.delenv("ZK_GKR_DENSE_TABLES")
+    spec[3].append(list(spec[3][0]))
+    proof = zk.gkr.prove(mk_circuit(zk, 0, spec), x)
+    want = O.gkr_prove(0, olayers(spec), x)                    # (the reference's own verifier may well reject this proof: evaluation counts the gate twice)
+    claims, co, ch = proof._flat
+    assert np.array_equal(claims, want["layer_claims"]) and np.array_equal(co, want["coeffs"]) and np.array_equal(ch, want["challenges"])
+    assert np.array_equal(proof.wb_evaluations, want["wb_evals"]) and np.array_equal(proof.wc_evaluations, want["wc_evals"])
+
+
+@pytest.mark.parametrize("field", [2, 3])
+def test_gkr_random_circuit_other_fields(zk, field):
+    """the same against the oracle on BN254 Fq / Fr, depth 6 (the one-pass alpha / beta fold over 1 .. 5 variables in those fields' arithmetic)"""
+    rng = random.Random(600 + field)
+    p = O.modulus(field)
+    spec = []
+    for i in range(6):
+        n_out, n_in = (1 << i), (1 << (i + 1))
+        spec.append([[rng.randrange(n_in), rng.randrange(n_in), o, rng.choice(["add", "mul"])] for o in range(n_out)])
+    check_against_oracle(zk, field, spec, [rng.randrange(p) for _ in range(1 << 6)])
+
+
 def test_gkr_shape_panics(zk):
     spec = [[[0, 1, 0, "mul"]], [[0, 1, 0, "add"], [2, 3, 1, "mul"], [4, 5, 2, "mul"], [6, 7, 3, "add"]]]
     with pytest.raises(zk.ReferencePanic):

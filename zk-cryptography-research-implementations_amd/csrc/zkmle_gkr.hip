@@ -4,6 +4,10 @@
 // the sumcheck itself, W evaluations) runs on the GPU through the table API.
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <algorithm>
+#include <array>
 #include <memory>
 #include <vector>
 
@@ -337,6 +341,66 @@ template <class F> int gkr_verify(const zk_gate *gates, const size_t *gate_count
     return ZK_OK;
 }
 
+bool dense_tables_forced() {
+    const char *e = getenv("ZK_GKR_DENSE_TABLES");                   // read per call: tests switch it
+    return e && e[0] == '1';
+}
+// Layer i (i >= 1) writes exactly the wires 0 .. 2^i - 1 and reads wires below 2^(i+1); layer 0 writes wire 0 (and maybe 1); 2^nlayers inputs; ops 0 / 1;
+// no gate twice in a layer (the dense predicates are indicators -- a repeated gate is ONE entry there but two terms of a gate list).  Everything else
+// (the shapes the reference panics on, repeated gates) stays with the dense path, which reproduces those outcomes.
+bool reference_shaped(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, size_t ninputs, size_t *lsz0) {
+    if (nlayers == 0 || nlayers > 24 || ninputs != ((size_t)1 << nlayers)) return false;
+    size_t off = 0;
+    std::vector<std::array<uint64_t, 4>> seen;
+    for (size_t L = 0; L < nlayers; L++) {
+        const size_t n = gate_counts[L], wout = L == 0 ? 2 : (size_t)1 << L, win = (size_t)1 << (L + 1);
+        if (n == 0) return false;
+        size_t mx = 0;
+        seen.clear();
+        for (size_t k = 0; k < n; k++) {
+            const zk_gate &g = gates[off + k];
+            if (g.out >= wout || g.left >= win || g.right >= win || g.op > 1) return false;
+            if (g.out > mx) mx = g.out;
+            seen.push_back({g.op, g.out, g.left, g.right});
+        }
+        if (L >= 1 && mx + 1 != wout) return false;
+        if (L == 0) *lsz0 = mx + 1;
+        std::sort(seen.begin(), seen.end());
+        if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return false;
+        off += n;
+    }
+    return true;
+}
+// the gate lists of the last circuit this thread proved, compiled (grouped by wire on the device): a prover calls prove() on one circuit many times
+struct CompiledCache {
+    std::vector<uint8_t> key;
+    zk_sparse_circuit *c = nullptr;
+    ~CompiledCache() { if (c) zk_sparse_circuit_free(c); }
+};
+int compiled_for(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, size_t ninputs, const zk_sparse_circuit **out) {
+    static thread_local CompiledCache cache;
+    int dev = 0;
+    ZK_HIP(hipGetDevice(&dev));
+    size_t total = 0;
+    for (size_t L = 0; L < nlayers; L++) total += gate_counts[L];
+    std::vector<uint8_t> key(sizeof(int) + (2 + nlayers) * sizeof(size_t) + total * sizeof(zk_gate));
+    uint8_t *w = key.data();
+    memcpy(w, &dev, sizeof dev); w += sizeof dev;
+    memcpy(w, &nlayers, sizeof nlayers); w += sizeof nlayers;
+    memcpy(w, &ninputs, sizeof ninputs); w += sizeof ninputs;
+    memcpy(w, gate_counts, nlayers * sizeof(size_t)); w += nlayers * sizeof(size_t);
+    memcpy(w, gates, total * sizeof(zk_gate));
+    if (!cache.c || cache.key != key) {
+        if (cache.c) { zk_sparse_circuit_free(cache.c); cache.c = nullptr; }
+        std::vector<uint32_t> out_bits(nlayers);
+        for (size_t L = 0; L < nlayers; L++) out_bits[L] = L == 0 ? 1u : (uint32_t)L;      // arithmetic_circuit.rs:166-178
+        ZK_TRY(zk_sparse_circuit_new(gates, gate_counts, nlayers, out_bits.data(), ninputs, &cache.c));
+        cache.key = std::move(key);
+    }
+    *out = cache.c;
+    return ZK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -383,6 +447,21 @@ int zk_gkr_prove(int field, const zk_gate *gates, const size_t *gate_counts, siz
         return ZK_E_ARG;
     if (nlayers > 1 && (!wb_evals || !wc_evals)) return ZK_E_ARG;
     ZK_TRY(require_device());
+    // A well-formed circuit of the reference's shape is proved from its gate lists (zkmle_gkr_sparse.hip): the same transcript, hence the same proof,
+    // without the dense add_i / mul_i tables (2^(3 i + 2) entries for layer i) -- ZK_GKR_DENSE_TABLES=1 keeps the reference's representation.
+    if (field_limbs64(field) > 0 && !dense_tables_forced()) {
+        size_t lsz0 = 0;
+        if (reference_shaped(gates, gate_counts, nlayers, ninputs, &lsz0)) {
+            const zk_sparse_circuit *c = nullptr;
+            ZK_TRY(compiled_for(gates, gate_counts, nlayers, ninputs, &c));
+            const size_t L64 = (size_t)field_limbs64(field);
+            uint64_t out2[2 * 6], outch[6];
+            ZK_TRY(zk_gkr_sparse_prove_compiled(field, c, inputs, ninputs, out2, claimed_sum, layer_claims, coeffs, challenges, wb_evals, wc_evals, outch, nullptr));
+            memcpy(circuit_output, out2, lsz0 * L64 * 8);          // a one-wire output layer was padded to two (gkr_protocol.rs:43-47)
+            *output_len = lsz0;
+            return ZK_OK;
+        }
+    }
     ZK_DISPATCH_FIELD(field, return gkr_prove<F>(gates, gate_counts, nlayers, inputs, ninputs, circuit_output, output_len, claimed_sum,
                                                  layer_claims, coeffs, challenges, wb_evals, wc_evals));
     return ZK_OK;
