@@ -1091,10 +1091,28 @@ def other_paths(zk, args):
     ok = zk.gkr.verify(circuit, gp, x)
     if not ok:
         raise SystemExit("bench.py: the dense GKR proof that was timed is rejected by gkr_protocol::verify")
-    out["gkr_dense"] = {"what": f"gkr_protocol::prove, reference-shaped circuit of depth {depth} (2^{depth} inputs; the last layer's dense add_i / mul_i have 2^{3 * (depth - 1) + 2} entries each, "
-                                f"its f(b,c) tables 2^{2 * (depth - 1) + 2}), BLS12-381 Fr", "ms": min(ts) * 1e3, "rounds": sum(2 * (i + 1) for i in range(depth)),
-                        "post_check": {"verifier_accepts": bool(ok)},
-                        "note": "the dense wiring tables are the reference's representation (exponential in the layer index); circuits of BASELINE config 4's size go through the gate-list prover (configs.cfg4)"}
+    # the same proof on the reference's dense add_i / mul_i tables (ZK_GKR_DENSE_TABLES=1, read per call): must be the same bytes
+    os.environ["ZK_GKR_DENSE_TABLES"] = "1"
+    try:
+        zk.gkr.prove(circuit, x)
+        td = []
+        for _ in range(3):
+            sync(); t0 = time.perf_counter()
+            gd = zk.gkr.prove(circuit, x)
+            sync(); td.append(time.perf_counter() - t0)
+    finally:
+        del os.environ["ZK_GKR_DENSE_TABLES"]
+    same = bool(all(np.array_equal(u, v) for u, v in zip(gp._flat, gd._flat)) and np.array_equal(gp.claimed_sum, gd.claimed_sum)
+                and np.array_equal(gp.wb_evaluations, gd.wb_evaluations) and np.array_equal(gp.wc_evaluations, gd.wc_evaluations))
+    if not same:
+        raise SystemExit("bench.py: gkr_protocol::prove from the gate lists and on the dense tables differ")
+    out["gkr_dense"] = {"what": f"gkr_protocol::prove, reference-shaped circuit of depth {depth} (2^{depth} inputs, layer i: 2^i gates), BLS12-381 Fr; proved from the gate lists "
+                                f"(one stream of kernels, lists compiled once per circuit), the reference's transcript and bytes", "ms": min(ts) * 1e3, "rounds": sum(2 * (i + 1) for i in range(depth)),
+                        "dense_tables_ms": min(td) * 1e3,
+                        "dense_tables_note": f"the same call with ZK_GKR_DENSE_TABLES=1: the reference's representation (the last layer's add_i / mul_i have 2^{3 * (depth - 1) + 2} entries each, "
+                                             f"its f(b,c) tables 2^{2 * (depth - 1) + 2})",
+                        "post_check": {"verifier_accepts": bool(ok), "both_representations_same_bytes": same},
+                        "note": "circuits of BASELINE config 4's size go through the same gate-list prover (configs.cfg4)"}
     return out
 
 
