@@ -1113,6 +1113,22 @@ def other_paths(zk, args):
                                              f"its f(b,c) tables 2^{2 * (depth - 1) + 2})",
                         "post_check": {"verifier_accepts": bool(ok), "both_representations_same_bytes": same},
                         "note": "circuits of BASELINE config 4's size go through the same gate-list prover (configs.cfg4)"}
+    # -- prove_succinct (succinct_gkr_protocol.rs:35-169): the same proof + commitment to the input layer + two KZG openings at the last layer's challenges
+    taus8 = MP.random(0, 1 << 4, 0x5EED0009).evaluated_values[:depth]
+    setup8 = zk.TrustedSetup.initialize_setup(taus8)
+    zk.gkr.prove_succinct(circuit, x, setup8)
+    tsu = []
+    for _ in range(3):
+        sync(); t0 = time.perf_counter()
+        sp = zk.gkr.prove_succinct(circuit, x, setup8)
+        sync(); tsu.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    oks = bool(zk.gkr.verify_succinct(circuit, sp, setup8))
+    vs = time.perf_counter() - t0
+    if not oks:
+        raise SystemExit("bench.py: the succinct GKR proof that was timed is rejected by verify_succinct")
+    out["gkr_succinct"] = {"what": f"succinct_gkr_protocol::prove_succinct on the same circuit: gkr::prove + commit_to_polynomial of the 2^{depth} inputs + two open_and_prove",
+                           "ms": min(tsu) * 1e3, "post_check": {"verify_succinct_accepts": oks, "verify_s": vs}}
     return out
 
 

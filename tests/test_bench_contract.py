@@ -72,6 +72,7 @@ def test_one_gpu_line_times_every_named_path_and_config():
     assert pa["setup_2p16"]["s"] > 0 and pa["kzg_commit_2p16"]["terms_per_s"] > 0
     assert pa["gkr_dense"]["post_check"]["verifier_accepts"] is True and pa["gkr_dense"]["post_check"]["both_representations_same_bytes"] is True
     assert pa["gkr_dense"]["dense_tables_ms"] > 0
+    assert pa["gkr_succinct"]["ms"] > 0 and pa["gkr_succinct"]["post_check"]["verify_succinct_accepts"] is True
     assert cf["cfg1"]["post_check"]["gpu_proof_equals_oracle_proof"] is True and cf["cfg1"]["cpu"]["cores"] == 1
     assert cf["cfg2"]["absorb_GBps"] > 0 and cf["cfg4"]["absorb_GBps"] > 0
     rk = cf["cfg4"]["round_kernels"]
