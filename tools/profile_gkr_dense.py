@@ -23,3 +23,9 @@ for _ in range(reps):
     gp = zk.gkr.prove(circuit, x)
     ts.append(time.perf_counter() - t0)
 print({"depth": depth, "ms_min": min(ts) * 1e3, "ms_median": sorted(ts)[len(ts) // 2] * 1e3, "verified": bool(zk.gkr.verify(circuit, gp, x))}, flush=True)
+tv = []
+for _ in range(5):
+    t0 = time.perf_counter()
+    okv = zk.gkr.verify(circuit, gp, x)
+    tv.append(time.perf_counter() - t0)
+print({"verify_ms_min": min(tv) * 1e3, "accepted": bool(okv)}, flush=True)
