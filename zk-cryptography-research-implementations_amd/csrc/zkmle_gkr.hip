@@ -375,10 +375,15 @@ bool reference_shaped(const zk_gate *gates, const size_t *gate_counts, size_t nl
 struct CompiledCache {
     std::vector<uint8_t> key;
     zk_sparse_circuit *c = nullptr;
+    size_t lsz0 = 0;
     ~CompiledCache() { if (c) zk_sparse_circuit_free(c); }
 };
-int compiled_for(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, size_t ninputs, const zk_sparse_circuit **out) {
+// *out = the compiled gate lists of this circuit if it is well-formed (null otherwise: the caller takes the dense tables).  The shape test (a sort
+// of each layer's gates) runs once per circuit: a call with the gates of the thread's last circuit is one memcmp.
+int compiled_for(const zk_gate *gates, const size_t *gate_counts, size_t nlayers, size_t ninputs, const zk_sparse_circuit **out, size_t *lsz0) {
     static thread_local CompiledCache cache;
+    *out = nullptr;
+    if (nlayers == 0 || nlayers > 24 || ninputs != ((size_t)1 << nlayers)) return ZK_OK;
     int dev = 0;
     ZK_HIP(hipGetDevice(&dev));
     size_t total = 0;
@@ -391,13 +396,17 @@ int compiled_for(const zk_gate *gates, const size_t *gate_counts, size_t nlayers
     memcpy(w, gate_counts, nlayers * sizeof(size_t)); w += nlayers * sizeof(size_t);
     memcpy(w, gates, total * sizeof(zk_gate));
     if (!cache.c || cache.key != key) {
-        if (cache.c) { zk_sparse_circuit_free(cache.c); cache.c = nullptr; }
+        size_t l0 = 0;
+        if (!reference_shaped(gates, gate_counts, nlayers, ninputs, &l0)) return ZK_OK;
+        if (cache.c) { zk_sparse_circuit_free(cache.c); cache.c = nullptr; cache.key.clear(); }
         std::vector<uint32_t> out_bits(nlayers);
         for (size_t L = 0; L < nlayers; L++) out_bits[L] = L == 0 ? 1u : (uint32_t)L;      // arithmetic_circuit.rs:166-178
         ZK_TRY(zk_sparse_circuit_new(gates, gate_counts, nlayers, out_bits.data(), ninputs, &cache.c));
         cache.key = std::move(key);
+        cache.lsz0 = l0;
     }
     *out = cache.c;
+    *lsz0 = cache.lsz0;
     return ZK_OK;
 }
 
@@ -451,9 +460,9 @@ int zk_gkr_prove(int field, const zk_gate *gates, const size_t *gate_counts, siz
     // without the dense add_i / mul_i tables (2^(3 i + 2) entries for layer i) -- ZK_GKR_DENSE_TABLES=1 keeps the reference's representation.
     if (field_limbs64(field) > 0 && !dense_tables_forced()) {
         size_t lsz0 = 0;
-        if (reference_shaped(gates, gate_counts, nlayers, ninputs, &lsz0)) {
-            const zk_sparse_circuit *c = nullptr;
-            ZK_TRY(compiled_for(gates, gate_counts, nlayers, ninputs, &c));
+        const zk_sparse_circuit *c = nullptr;
+        ZK_TRY(compiled_for(gates, gate_counts, nlayers, ninputs, &c, &lsz0));
+        if (c) {
             const size_t L64 = (size_t)field_limbs64(field);
             uint64_t out2[2 * 6], outch[6];
             ZK_TRY(zk_gkr_sparse_prove_compiled(field, c, inputs, ninputs, out2, claimed_sum, layer_claims, coeffs, challenges, wb_evals, wc_evals, outch, nullptr));
