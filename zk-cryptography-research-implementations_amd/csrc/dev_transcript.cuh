@@ -636,6 +636,11 @@ struct TailArgs {
     size_t fin_slot;         // ntab final values (only written when fin_slot != ~0)
     uint64_t seq0;           // host-assisted step: request number of the tail's first round; the final values go out as one more request
     uint64_t *trace;         // ZK_TAIL_TRACE=1: 6 wall_clock64() stamps per round (measurement only), else nullptr
+    // first_evals: `in` are the tables of round `round` BEFORE any exchange -- the launch starts with that round's evaluations (what round_evals_kernel
+    // + its exchange do for a long table: 15-17 us as a launch of its own, 16 of them in a depth-8 GKR proof) and goes on as usual.  with_claim /
+    // claim_slot: proof[claim_slot] is absorbed in front of that first message (sumcheck_gkr_protocol.rs:35).
+    int first_evals, with_claim;
+    size_t claim_slot;
 };
 #define ZK_TAIL_STAMP(k) do { if (a.trace && tid == 0) a.trace[6 * j + (k)] = wall_clock64(); } while (0)
 
@@ -649,12 +654,51 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
     if (tid < 25 && !mb) S.st[tid] = a.ctx.sponge->a[tid];
     uint32_t fill = mb ? 0u : a.ctx.sponge->fill;
     uint64_t seq = a.seq0;
-    Fe<F> r = fe_load<F>(a.ctx.proof, a.chal_base + a.per * a.round);
+    Fe<F> r = fe_zero<F>();
     // table k of the current round: the caller's tables first, then slice k of the previous round's output buffer
     const char *prev = nullptr;
     size_t cl = a.len, round = a.round;
     int j = 0;
     __syncthreads();
+    if (a.first_evals) {                                     // round `round` itself: evaluations of the tables as they are, exchange, challenge
+        const size_t half = cl / 2;
+        Wide<F> acc[NFAC + 1];
+#pragma unroll
+        for (int t = 0; t <= NFAC; t++) acc[t] = wide_zero<F>();
+        for (size_t i = tid; i < half; i += kTailBlock) {
+            for (int p = 0; p < a.nprod; p++) {
+                Fe<F> lo[NFAC], hi[NFAC];
+#pragma unroll
+                for (int f = 0; f < NFAC; f++) {
+                    if (NFAC == 2 && f == 1 && a.tabs.in[p * NFAC + 1] == nullptr) { lo[1] = hi[1] = const_factor<F>(a.tabs, p); continue; }
+                    lo[f] = fe_load<F>(a.tabs.in[p * NFAC + f], i);
+                    hi[f] = fe_load<F>(a.tabs.in[p * NFAC + f], i + half);
+                }
+                accumulate_terms<F, NFAC>(lo, hi, acc);
+            }
+        }
+        Fe<F> tot;
+        const size_t lanes0 = half < (size_t)kTailBlock ? half : (size_t)kTailBlock;
+        if (block_reduce_wide<F, NFAC + 1>(acc, sh, tot, (int)((lanes0 + 63) / 64))) S.ev[tid] = tot;
+        __syncthreads();
+        if (tid < 64) {
+            if (mb) {
+                mailbox_post<F>(mb, mb->ev, S.ev, NFAC + 1, seq, lane);
+                const Fe<F> rn = mailbox_wait_challenge<F>(mb, seq, lane);
+                if (lane == 0) {
+                    S.chal = rn;
+                    fe_store<F>(a.ctx.proof, a.chal_base + a.per * round, S.chal);
+                }
+                seq++;
+            } else {
+                round_message_and_challenge<F>(S, a.ctx, a.with_claim, a.claim_slot, a.msg_base + a.per * round, a.chal_base + a.per * round, fill, lane);
+            }
+        }
+        __syncthreads();
+        r = S.chal;
+    } else {
+        r = fe_load<F>(a.ctx.proof, a.chal_base + a.per * a.round);
+    }
     while (cl >= 4) {                                        // fold by r AND evaluate the next round (sumcheck_kernels.cuh)
         const size_t q = cl / 4, ol = cl / 2;
         char *dst = (char *)a.buf[j & 1];

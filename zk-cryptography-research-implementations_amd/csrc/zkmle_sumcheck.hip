@@ -483,11 +483,14 @@ template <class F> struct DeviceRounds {
         return ZK_OK;
     }
     // every remaining round of a sumcheck whose tables have <= kTailLen entries, one launch (dev_transcript.cuh)
+    // first_evals: the tail starts with round `round`'s own evaluations and exchange (no round_evals launch in front of it); with_claim /
+    // claim_slot as for that round
     int launch_tail(const SumPolyTables &tabs, void *buf0, void *buf1, int nprod, int nfac, size_t len, int mode, size_t round,
-                    size_t msg_base, size_t chal_base, size_t per, size_t fin_slot) {
+                    size_t msg_base, size_t chal_base, size_t per, size_t fin_slot, int first_evals = 0, int with_claim = 0, size_t claim_slot = 0) {
         TailArgs a{};
         a.tabs = tabs; a.buf[0] = buf0; a.buf[1] = buf1; a.nprod = nprod; a.ntab = nprod * nfac; a.len = len;
         a.ctx = ctx(nfac + 1, mode); a.round = round; a.msg_base = msg_base; a.chal_base = chal_base; a.per = per; a.fin_slot = fin_slot;
+        a.first_evals = first_evals; a.with_claim = with_claim; a.claim_slot = claim_slot;
         static const bool want_trace = [] { const char *e = getenv("ZK_TAIL_TRACE"); return e && e[0] == '1'; }();
         if (want_trace) {                                   // measurement only: per-phase stamps of this tail, printed after the launch
             ZK_TRY(tail_trace.alloc(6 * 16 * sizeof(uint64_t)));
@@ -497,6 +500,8 @@ template <class F> struct DeviceRounds {
         if (host_mode) {
             a.seq0 = nreq() + 1;
             size_t rd = round;
+            if (first_evals)                                 // round `round` itself: the request round_fin() would have registered for a launch of its own
+                push_req(Req{kRound, mode, nfac + 1, with_claim, 0, 0, claim_slot, msg_base + per * rd, chal_base + per * rd, 0, {0, 0, 0, 0, 0, 0, 0}});
             for (size_t cl = len; cl >= 4; cl /= 2) {        // one request per fused round of the tail, then its final values
                 rd++;
                 push_req(Req{kRound, mode, nfac + 1, 0, 0, 0, 0, msg_base + per * rd, chal_base + per * rd, 0, {0, 0, 0, 0, 0, 0, 0}});
@@ -926,7 +931,8 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
     auto takes_uniform = [&](size_t cl_folded) {                     // cl_folded: the length of the tables that challenge folds
         return dr.host_mode && nfac == 2 && LazyProducts<F>::value && cl_folded > tail_from0 && !fold_round_takes_split((int)nprod, (int)nfac, cl_folded / 4, true);
     };
-    {   // round 0 evaluations
+    const bool tail_takes_all = len <= tail_from0;                   // every round, the first one's evaluations included, in the one-workgroup tail
+    if (!tail_takes_all) {   // round 0 evaluations
         size_t half = len / 2;
         int grid = reduce_grid_for(half);
         // host-assisted step only: the host keeps the running claim (the device variant reads the previous round's slots, which round 0 has not)
@@ -972,7 +978,7 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
         cl = ol;
     }
     // rounds on <= kTailLen entries, the last fold and the final values: one launch
-    return dr.launch_tail(tabs, dst, other, (int)nprod, (int)nfac, cl, 1, round, s0, s0 + npts, per, fin_slot);
+    return dr.launch_tail(tabs, dst, other, (int)nprod, (int)nfac, cl, 1, round, s0, s0 + npts, per, fin_slot, tail_takes_all ? 1 : 0, with_claim, claim_slot);
 }
 
 // `const_factors` (nprod elements, may be null): where tables[p * 2 + 1] is null the second factor of product p is that constant
