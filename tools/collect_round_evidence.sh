@@ -12,6 +12,9 @@ python3 $R/tools/rocprof_summary.py /tmp/p_sp fold_round_evals_kernel > $R/gpuru
 python3 $R/tools/rocprof_timeline.py /tmp/p_sp 33 "phase1_tables_kernel<zk::Fr381, true>" > $R/gpurun_out/r4e/gkr_sparse_config4_layer_timeline.txt 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/p_b24 -- python3 $R/tools/profile_config5_sumcheck.py 24 > $R/gpurun_out/r4e/basic_run.log 2>&1
 python3 $R/tools/rocprof_timeline.py /tmp/p_b24 4 "seg_sums_kernel" > $R/gpurun_out/r4e/basic_sumcheck_2p24_trace.txt 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/p_gd -- python3 $R/tools/profile_gkr_dense.py 8 5 > $R/gpurun_out/r4e/gkr_dense_run.log 2>&1
+python3 $R/tools/rocprof_summary.py /tmp/p_gd > $R/gpurun_out/r4e/gkr_reference_shape_depth8_kernel_summary.txt 2>&1
+grep -E "depth|verify" $R/gpurun_out/r4e/gkr_dense_run.log >> $R/gpurun_out/r4e/gkr_reference_shape_depth8_kernel_summary.txt
 cd $R
 timeout -k 10 120 tools/microbench_round.bin 22 100 1536 > gpurun_out/r4e/microbench_round_2p22.jsonl 2>&1
 timeout -k 10 120 tools/microbench_round.bin 22 100 1536 3 >> gpurun_out/r4e/microbench_round_2p22.jsonl 2>&1

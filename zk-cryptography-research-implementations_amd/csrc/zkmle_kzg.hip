@@ -27,6 +27,9 @@ struct zk_g1_bases {
     void *pre_u = nullptr;
     int pre_c = 0;
     unsigned pre_nwin = 0;
+    // prove_succinct opens twice on the same powers at every call: the pre-summed levels (zk_kzg_opening_key_new, milliseconds even for 2^8 points) are
+    // built at the first one and kept with the points they are sums of
+    struct zk_kzg_opening_key *own_key = nullptr;
 };
 struct zk_kzg_opening_key {
     // level[t] (t = 1..nvars): 2^(nvars - t) pre-summed affine bases B^(t)_k = sum_{h < 2^t} B_{h 2^(nvars-t) + k}
@@ -525,6 +528,7 @@ int zk_g1_bases_free(zk_g1_bases *b) {
     if (b->dptr) ZK_HIP(hipFree(b->dptr));
     if (b->dptr_u) ZK_HIP(hipFree(b->dptr_u));
     if (b->pre_u) ZK_HIP(hipFree(b->pre_u));
+    if (b->own_key) zk_kzg_opening_key_free(b->own_key);
     delete b;
     return ZK_OK;
 }
@@ -801,9 +805,9 @@ extern "C++" int zk::kzg_open_core(const zk_table *poly, const zk_g1_bases *g1_p
     zk_table *sub = nullptr, *nxt = nullptr;
     if (rc == ZK_OK && v_given) memcpy(evaluation, v_given, 32);
     if (rc == ZK_OK && !v_given) rc = zk_mle_evaluate(poly, opening, nopen, evaluation);        // :70
-    if (rc == ZK_OK) rc = zk_table_alloc(ZK_FR381, poly->len, &sub);
+    if (rc == ZK_OK) rc = table_alloc_pooled(ZK_FR381, poly->len, &sub);                        // pooled: a small opening is not two hipMalloc / hipFree pairs
     if (rc == ZK_OK) rc = zk_mle_sub_scalar(poly, evaluation, sub, nullptr);                    // :74-80
-    if (rc == ZK_OK && poly->len >= 2) rc = zk_table_alloc(ZK_FR381, poly->len / 2, &nxt);
+    if (rc == ZK_OK && poly->len >= 2) rc = table_alloc_pooled(ZK_FR381, poly->len / 2, &nxt);
     // quotients of the batched (small) levels are collected, zero-padded, in one scalar buffer [j][2^small_bits];
     // those of the large levels lie end to end in `bigq` (level i at offset len - len / 2^i)
     const bool batched = key->small_u != nullptr && rc == ZK_OK;
@@ -883,7 +887,10 @@ int zk_gkr_prove_succinct(const zk_gate *gates, const size_t *gate_counts, size_
                           uint64_t *rc_proofs) {
     if (!g1_powers || !commitment12 || !rb_evaluation || !rb_proofs || !rc_evaluation || !rc_proofs || nlayers == 0) return ZK_E_ARG;
     zk_table *in = nullptr;
-    ZK_TRY(zk_table_upload(ZK_FR381, inputs, ninputs, &in));                    // MultilinearPolynomial::new(inputs) :41
+    if (!inputs) return ZK_E_ARG;
+    if (!is_pow2(ninputs)) return ZK_E_NOT_POW2;                                 // MultilinearPolynomial::new(inputs) :41
+    ZK_TRY(table_alloc_pooled(ZK_FR381, ninputs, &in));
+    if (zk::memcpy_on_stream(in->dptr, inputs, ninputs * 32, hipMemcpyHostToDevice) != hipSuccess) { zk_table_free(in); return ZK_E_HIP; }
     int rc = zk_kzg_commit(in, g1_powers, commitment12);                         // :42-44
     // the layer loop is gkr_protocol::prove's (same transcript schedule; rb / rc are taken from
     // every layer's challenges here, :121-126, which only matters for the last layer's values)
@@ -895,11 +902,15 @@ int zk_gkr_prove_succinct(const zk_gate *gates, const size_t *gate_counts, size_
         for (size_t L = 0; L + 1 < nlayers; L++) off += zk_gkr_rounds(L);
         size_t rounds = zk_gkr_rounds(nlayers - 1), mid = rounds / 2;
         const uint64_t *rb = challenges + off * 4, *rcv = challenges + (off + mid) * 4;
-        zk_kzg_opening_key *key = nullptr;
-        rc = (in->len == g1_powers->n) ? zk_kzg_opening_key_new(g1_powers, &key) : ZK_E_KZG_LEN;
+        zk_g1_bases *mb = const_cast<zk_g1_bases *>(g1_powers);                  // a cache of sums of the same immutable points (as bases_u)
+        static std::mutex key_mu;
+        {
+            std::lock_guard<std::mutex> lk(key_mu);
+            rc = in->len != g1_powers->n ? ZK_E_KZG_LEN : (mb->own_key ? ZK_OK : zk_kzg_opening_key_new(g1_powers, &mb->own_key));
+        }
+        const zk_kzg_opening_key *key = mb->own_key;
         if (rc == ZK_OK) rc = zk_kzg_open(in, g1_powers, key, rb, mid, n_g2, rb_evaluation, rb_proofs);            // :154-155
         if (rc == ZK_OK) rc = zk_kzg_open(in, g1_powers, key, rcv, rounds - mid, n_g2, rc_evaluation, rc_proofs);  // :156-157
-        zk_kzg_opening_key_free(key);
     }
     zk_table_free(in);
     return rc;
