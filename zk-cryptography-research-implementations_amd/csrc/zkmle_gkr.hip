@@ -157,13 +157,13 @@ template <class F> int add_mul_mle(const zk_gate *g, size_t ngates, size_t layer
 }
 
 // what a proof uploads ONCE instead of once per layer: every layer's wiring positions and every layer's evaluations
-struct PoolBlock2 {
+struct PooledBlock {
     void *p = nullptr;
-    ~PoolBlock2() { pool_free(p); }
+    ~PooledBlock() { pool_free(p); }
     int alloc(size_t bytes) { return pool_alloc(bytes ? bytes : 8, &p); }
 };
 struct LayerPositions {
-    PoolBlock2 dev;
+    PooledBlock dev;
     std::vector<size_t> off, na, nm;
     const uint64_t *at(size_t L) const { return (const uint64_t *)dev.p + off[L]; }
 };
@@ -234,7 +234,7 @@ template <class F> int gkr_prove(const zk_gate *gates, const size_t *gate_counts
     // one upload each for what every layer needs from the host: the wiring positions and the layer evaluations (w_i are views into the block)
     LayerPositions lp;
     ZK_TRY(upload_positions(gates, gate_counts, nlayers, lp));
-    PoolBlock2 wdev;
+    PooledBlock wdev;
     ZK_TRY(wdev.alloc(ce.evals.size() * 8));
     ZK_HIP(zk::memcpy_on_stream(wdev.p, ce.evals.data(), ce.evals.size() * 8, hipMemcpyHostToDevice));
     for (size_t L = 0; L < nlayers; L++) {                                           // :57
