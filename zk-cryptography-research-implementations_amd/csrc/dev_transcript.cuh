@@ -641,6 +641,9 @@ struct TailArgs {
     // claim_slot: proof[claim_slot] is absorbed in front of that first message (sumcheck_gkr_protocol.rs:35).
     int first_evals, with_claim;
     size_t claim_slot;
+    // two_rounds (host-assisted step, two-factor products; 0 = never): while the tables have at most this many (product, quad) pairs, TWO rounds per
+    // exchange (see the kernel)
+    int two_rounds;
 };
 #define ZK_TAIL_STAMP(k) do { if (a.trace && tid == 0) a.trace[6 * j + (k)] = wall_clock64(); } while (0)
 
@@ -699,7 +702,108 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
     } else {
         r = fe_load<F>(a.ctx.proof, a.chal_base + a.per * a.round);
     }
-    while (cl >= 4) {                                        // fold by r AND evaluate the next round (sumcheck_kernels.cuh)
+    // Two rounds per exchange.  A round on a short table is latency: ~3 us of arithmetic, then the workgroup's reduction (2 us) and the exchange with the
+    // host (3.4 us) -- and the round AFTER it is a polynomial in this round's challenge whose coefficients are known before the challenge is.  With the
+    // folded tables T' (4 q' entries each) cut into quads a = T'[i], b = T'[i + q'], c = T'[i + 2 q'], d = T'[i + 3 q'] (first variable: a,b | c,d;
+    // second: a | b), per product of two factors:
+    //   round A (first variable):  e(0) = P0 + P1, e(1) = Q0 + Q1, e(inf) = D0 + D1,   P = a a', b b';  Q = c c', d d';  D = (c - a)(c' - a'), (d - b)(d' - b')
+    //   round B after folding by rA: lo = a + rA (c - a), hi = b + rA (d - b):
+    //     e(0) = lo lo' = P0 + rA (Q0 - P0 - D0) + rA^2 D0,   e(1) = P1 + rA (Q1 - P1 - D1) + rA^2 D1,
+    //     e(inf) = (hi - lo)(hi' - lo') = EE + rA (FF - EE - GG) + rA^2 GG,   E = b - a, F = d - c, G = F - E.
+    // Nine sums -- as many products as the two rounds take one after the other -- leave in ONE post; the host runs both transcript steps
+    // (zkmle_sumcheck.hip serve_round2: the same messages, the same bytes absorbed) and answers with both challenges.  One WAVE per sum: lane m of
+    // wave s takes (product, quad) m of sum s -- one product per lane, one DPP reduction per wave; wave 0 takes the ninth sum as well.
+    // (A first form with one lane per (product, quad) doing all nine products lost to the single rounds: 256 VGPRs, spills, a nine-sum reduction.)
+    __shared__ Fe<F> ev9[9], ch2[2];                         // two rounds per exchange (below)
+    const unsigned wv = tid >> 6;
+    for (;;) {
+        if constexpr (NFAC == 2) {
+            while (mb && a.two_rounds && cl >= 8 && (size_t)a.nprod * (cl / 8) <= (size_t)a.two_rounds) {
+                const size_t ol = cl / 2, qq = ol / 4, o2 = ol / 2;
+                char *d1 = (char *)a.buf[j & 1], *d2 = (char *)a.buf[(j + 1) & 1];
+                {   // fold by r: one lane task per (table, output index)
+                    const Multiplier<F> mr(r);
+                    for (size_t t = tid; t < (size_t)a.ntab * ol; t += kTailBlock) {
+                        const size_t k = t / ol, idx = t - k * ol;
+                        if (a.tabs.in[k] == nullptr) continue;
+                        const void *src = prev ? (const void *)(prev + k * cl * esz) : a.tabs.in[k];
+                        const Fe<F> x = fe_load<F>(src, idx), y = fe_load<F>(src, idx + ol);
+                        fe_store<F>(d1 + k * ol * esz, idx, fe_add<F>(x, mr.times(fe_sub<F>(y, x))));
+                    }
+                }
+                __syncthreads();
+                {
+                    const size_t M = (size_t)a.nprod * qq;                 // (product, quad) pairs: <= kTwoRoundPairs
+#pragma unroll 1
+                    for (unsigned pass = 0; pass < 2; pass++) {            // every wave its own sum; wave 0 the ninth one after that
+                        if (pass == 1 && wv != 0) break;
+                        const unsigned kind = pass == 0 ? wv : 8u;
+                        Wide<F> acc[1] = {wide_zero<F>()};
+#pragma unroll 1
+                        for (size_t m = lane; m < M; m += 64) {
+                            const size_t p = m / qq, i = m - p * qq;
+                            // the operand pair of sum `kind` at this lane's quad: x (first factor), y (second factor); at most two entries of T' each
+                            // kinds: 0 P0 = a a', 1 P1 = b b', 2 Q0 = c c', 3 Q1 = d d', 4 D0 = (c-a)(..), 5 D1 = (d-b)(..), 6 EE = (b-a)(..), 7 FF = (d-c)(..), 8 GG = ((d-c)-(b-a))(..)
+                            Fe<F> o[2];
+#pragma unroll
+                            for (int f = 0; f < 2; f++) {
+                                if (a.tabs.in[p * 2 + f] == nullptr) {                     // a constant factor: a = b = c = d
+                                    o[f] = kind < 4 ? const_factor<F>(a.tabs, (int)p) : fe_zero<F>();
+                                    continue;
+                                }
+                                const void *tb = d1 + (p * 2 + f) * ol * esz;
+                                if (kind < 4) {
+                                    o[f] = fe_load<F>(tb, i + kind * qq);
+                                } else if (kind < 8) {
+                                    const size_t hi = kind == 4 ? 2 : kind == 5 ? 3 : kind == 6 ? 1 : 3, lo = kind == 4 ? 0 : kind == 5 ? 1 : kind == 6 ? 0 : 2;
+                                    o[f] = fe_sub<F>(fe_load<F>(tb, i + hi * qq), fe_load<F>(tb, i + lo * qq));
+                                } else {
+                                    o[f] = fe_sub<F>(fe_sub<F>(fe_load<F>(tb, i + 3 * qq), fe_load<F>(tb, i + 2 * qq)), fe_sub<F>(fe_load<F>(tb, i + qq), fe_load<F>(tb, i)));
+                                }
+                            }
+                            wide_add_fe<F>(acc[0], fe_mul<F>(o[0], o[1]));
+                        }
+                        wave_reduce_wide<F, 1>(acc);
+                        if (lane == 63) ev9[kind] = wide_reduce<F>(acc[0]);
+                    }
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    if (lane < 9) {
+    #pragma unroll
+                        for (int w = 0; w < F::N; w++) mb->big[lane * 12 + w] = ev9[lane].l[w];
+                    }
+                    __threadfence_system();
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) __atomic_store_n(&mb->gpu_seq, seq, __ATOMIC_RELEASE);
+                    const Fe<F> rr = mailbox_wait_challenges<F>(mb, seq, lane, 2u);
+                    if (lane < 2) {
+                        ch2[lane] = rr;
+                        fe_store<F>(a.ctx.proof, a.chal_base + a.per * (round + 1 + lane), rr);
+                    }
+                    seq++;
+                }
+                __syncthreads();
+                {   // fold T' by the first of the two challenges; the second one folds the result in the next iteration
+                    const Multiplier<F> mr(ch2[0]);
+                    for (size_t t = tid; t < (size_t)a.ntab * o2; t += kTailBlock) {
+                        const size_t k = t / o2, idx = t - k * o2;
+                        if (a.tabs.in[k] == nullptr) continue;
+                        const void *src = d1 + k * ol * esz;
+                        const Fe<F> x = fe_load<F>(src, idx), y = fe_load<F>(src, idx + o2);
+                        fe_store<F>(d2 + k * o2 * esz, idx, fe_add<F>(x, mr.times(fe_sub<F>(y, x))));
+                    }
+                }
+                __syncthreads();
+                r = ch2[1];
+                prev = d2;
+                cl = o2;
+                round += 2;
+                j += 2;
+            }
+        }
+        if (cl < 4) break;
+        // fold by r AND evaluate the next round (sumcheck_kernels.cuh)
         const size_t q = cl / 4, ol = cl / 2;
         char *dst = (char *)a.buf[j & 1];
         ZK_TAIL_STAMP(0);

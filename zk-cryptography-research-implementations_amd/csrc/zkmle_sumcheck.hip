@@ -170,7 +170,7 @@ template <class F> struct DeviceRounds {
     std::vector<Fe<F>> hs;                             // the proof slots, host copy
     std::vector<Fe<F>> hbasis;                         // basis[i * npts + d], stored form
     struct Req { int kind, mode, npts, with_claim, derive1, ntab; size_t claim_slot, msg_slot, chal_slot, fin_slot, s[7]; };
-    enum { kRound = 0, kFinal = 1, kLink = 2, kMulti = 3 };
+    enum { kRound = 0, kFinal = 1, kLink = 2, kMulti = 3, kRound2 = 4 };
     std::vector<Req> reqs;                             // appended by the proving thread, consumed in order by the service thread
     std::mutex req_mu;
     size_t served = 0;                                 // service thread only
@@ -287,6 +287,51 @@ template <class F> struct DeviceRounds {
         }
         hs[q.chal_slot] = r;
     }
+    // one transcript step of a two-factor GKR round from its evaluations at 0, 1, infinity (sumcheck_gkr_protocol.rs:46-55): absorbs the coefficients
+    // (canonical, little-endian), samples the challenge, keeps the proof's copy and the running claim
+    Fe<F> step_gkr3(const Fe<F> (&ev)[3], size_t msg_slot, size_t chal_slot) {
+        const size_t n2 = 9;
+        uint8_t bytes[3 * 4 * F::N];
+        Fe<F> c[3];
+        for (int d = 0; d < 3; d++) {
+            Fe<F> cc = fe_mul<F>(ev[0], hbasis[n2 + d]);
+            c[d] = fe_mul<F>(ev[0], hbasis[d]);
+            for (int i = 1; i < 3; i++) {
+                cc = fe_add<F>(cc, fe_mul<F>(ev[i], hbasis[n2 + (size_t)i * 3 + d]));
+                c[d] = fe_add<F>(c[d], fe_mul<F>(ev[i], hbasis[(size_t)i * 3 + d]));
+            }
+            memcpy(bytes + (size_t)d * 4 * F::N, cc.l, 4 * F::N);
+            hs[msg_slot + d] = c[d];
+        }
+        htr->append(bytes, sizeof bytes);
+        const Fe<F> r = htr->template random_challenge_as_field_element<F>();
+        hs[chal_slot] = r;
+        running_claim = fe_add<F>(fe_mul<F>(fe_add<F>(fe_mul<F>(c[2], r), c[1]), r), c[0]);
+        return r;
+    }
+    // TWO rounds of a two-factor GKR sumcheck from the nine sums the tail posts (dev_transcript.cuh, sumcheck_tail_kernel): round A's evaluations are sums of
+    // them; round B's are polynomials in round A's challenge with those sums as coefficients.  q.s[0] = slots per round.
+    void serve_round2(const Req &q, uint64_t seq) {
+        Fe<F> S[9];
+        for (int t = 0; t < 9; t++) S[t] = mb_get(mb->big + 12 * t);
+        const Fe<F> &P0 = S[0], &P1 = S[1], &Q0 = S[2], &Q1 = S[3], &D0 = S[4], &D1 = S[5], &EE = S[6], &FF = S[7], &GG = S[8];
+        const size_t per = q.s[0];
+        const Fe<F> evA[3] = {fe_add<F>(P0, P1), fe_add<F>(Q0, Q1), fe_add<F>(D0, D1)};
+        const Fe<F> rA = step_gkr3(evA, q.msg_slot, q.chal_slot);
+        auto quad = [&](const Fe<F> &k0, const Fe<F> &k1, const Fe<F> &k2) {          // k0 + rA (k1 - k0 - k2) + rA^2 k2
+            const Fe<F> mid = fe_sub<F>(fe_sub<F>(k1, k0), k2);
+            return fe_add<F>(fe_mul<F>(fe_add<F>(fe_mul<F>(k2, rA), mid), rA), k0);
+        };
+        const Fe<F> evB[3] = {quad(P0, Q0, D0), quad(P1, Q1, D1), quad(EE, FF, GG)};
+        const Fe<F> rB = step_gkr3(evB, q.msg_slot + per, q.chal_slot + per);
+        const Fe<F> both[2] = {rA, rB};
+        for (int i = 0; i < 2; i++)
+            for (int k = 0; k < F::N; k++) __atomic_store_n(&mb->ans8[i][1 + k], both[i].l[k], __ATOMIC_RELAXED);
+        for (int i = 0; i < 2; i++) {                                          // the answer lines' tags last (dev_transcript.cuh)
+            __atomic_store_n(&mb->ans8[i][0], (uint32_t)seq, __ATOMIC_RELEASE);
+            __atomic_store_n(&mb->ans8[i][15], (uint32_t)seq, __ATOMIC_RELEASE);
+        }
+    }
     // basic sumcheck, q.npts rounds from the 2^npts segment sums of the current table (basic_multi.cuh): the basic sumcheck on the
     // table of the sums, S -- round i sends its two half sums and folds its top variable by the challenge
     void serve_multi(const Req &q, uint64_t seq) {
@@ -366,6 +411,7 @@ template <class F> struct DeviceRounds {
             if (q.kind == kRound) serve_round(q, seq);           // publishes its answer itself, as early as it can
             else {
                 if (q.kind == kMulti) serve_multi(q, seq);
+                else if (q.kind == kRound2) serve_round2(q, seq);
                 else if (q.kind == kLink) serve_link(q);
                 else for (int k = 0; k < q.ntab; k++) hs[q.fin_slot + k] = mb_get(mb->fin + 12 * k);
                 __atomic_store_n(&mb->cpu_seq, seq, __ATOMIC_RELEASE);
@@ -491,6 +537,9 @@ template <class F> struct DeviceRounds {
         a.tabs = tabs; a.buf[0] = buf0; a.buf[1] = buf1; a.nprod = nprod; a.ntab = nprod * nfac; a.len = len;
         a.ctx = ctx(nfac + 1, mode); a.round = round; a.msg_base = msg_base; a.chal_base = chal_base; a.per = per; a.fin_slot = fin_slot;
         a.first_evals = first_evals; a.with_claim = with_claim; a.claim_slot = claim_slot;
+        // ZK_TAIL_TWO_ROUNDS = the most (product, quad) pairs a two-round exchange takes (0: never; measurement / fallback switch)
+        static const int two = [] { const char *e = getenv("ZK_TAIL_TWO_ROUNDS"); int v = e ? atoi(e) : 128; return v < 0 ? 0 : (v > 4096 ? 4096 : v); }();   // r4 sweep (0 / 64 / 128 / 256 / 512): 4 x 2^12 0.155 / 0.145 / 0.134 / 0.139 / 0.139 ms, depth-8 GKR 1.26 / 1.20 / 1.18 / 1.17 / 1.18
+        a.two_rounds = (host_mode && nfac == 2 && mode == 1) ? two : 0;
         static const bool want_trace = [] { const char *e = getenv("ZK_TAIL_TRACE"); return e && e[0] == '1'; }();
         if (want_trace) {                                   // measurement only: per-phase stamps of this tail, printed after the launch
             ZK_TRY(tail_trace.alloc(6 * 16 * sizeof(uint64_t)));
@@ -502,9 +551,17 @@ template <class F> struct DeviceRounds {
             size_t rd = round;
             if (first_evals)                                 // round `round` itself: the request round_fin() would have registered for a launch of its own
                 push_req(Req{kRound, mode, nfac + 1, with_claim, 0, 0, claim_slot, msg_base + per * rd, chal_base + per * rd, 0, {0, 0, 0, 0, 0, 0, 0}});
-            for (size_t cl = len; cl >= 4; cl /= 2) {        // one request per fused round of the tail, then its final values
-                rd++;
-                push_req(Req{kRound, mode, nfac + 1, 0, 0, 0, 0, msg_base + per * rd, chal_base + per * rd, 0, {0, 0, 0, 0, 0, 0, 0}});
+            // the kernel's own schedule (dev_transcript.cuh): single rounds while the tables are long, two rounds per exchange once (product, quad) pairs fit a wave
+            for (size_t cl = len; cl >= 4;) {
+                if (a.two_rounds && cl >= 8 && (size_t)nprod * (cl / 8) <= (size_t)a.two_rounds) {
+                    push_req(Req{kRound2, mode, nfac + 1, 0, 0, 0, 0, msg_base + per * (rd + 1), chal_base + per * (rd + 1), 0, {per, 0, 0, 0, 0, 0, 0}});
+                    rd += 2;
+                    cl /= 4;
+                } else {
+                    rd++;
+                    push_req(Req{kRound, mode, nfac + 1, 0, 0, 0, 0, msg_base + per * rd, chal_base + per * rd, 0, {0, 0, 0, 0, 0, 0, 0}});
+                    cl /= 2;
+                }
             }
             const bool want_fin = fin_slot != ~(size_t)0;
             push_req(Req{kFinal, mode, nfac + 1, 0, 0, want_fin ? nprod * nfac : 0, 0, 0, 0, want_fin ? fin_slot : 0, {0, 0, 0, 0, 0, 0, 0}});
