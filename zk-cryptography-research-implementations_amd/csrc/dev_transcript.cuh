@@ -333,6 +333,18 @@ template <class F> __device__ __forceinline__ void round_finish_in_producer(cons
         }
         e = wide_reduce<F>(w);
     }
+    if (f.per2) {                                            // two rounds: nine sums out, two challenges back (zkmle_sumcheck.hip serve_round2)
+        if ((int)lane < f.npts) {
+#pragma unroll
+            for (int k = 0; k < F::N; k++) f.mb->big[lane * 12 + k] = e.l[k];
+        }
+        __threadfence_system();
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __atomic_store_n(&f.mb->gpu_seq, f.seq, __ATOMIC_RELEASE);
+        const Fe<F> rr = mailbox_wait_challenges<F>(f.mb, f.seq, lane, 2u);
+        if (lane < 2) fe_store<F>(f.proof, f.chal_slot + f.per2 * lane, rr);
+        return;
+    }
     if ((int)lane < f.npts) {                                // the evaluations, as mailbox_post lays them out
 #pragma unroll
         for (int k = 0; k < F::N; k++) f.mb->ev[lane * 12 + k] = e.l[k];
@@ -641,6 +653,9 @@ struct TailArgs {
     // claim_slot: proof[claim_slot] is absorbed in front of that first message (sumcheck_gkr_protocol.rs:35).
     int first_evals, with_claim;
     size_t claim_slot;
+    // pending2: TWO challenges are pending at entry (rounds `round` and `round + 1`, after a two-round exchange of split2_round_kernel): the tables are
+    // folded by the first one before anything else
+    int pending2;
     // two_rounds (host-assisted step, two-factor products; 0 = never): while the tables have at most this many (product, quad) pairs, TWO rounds per
     // exchange (see the kernel)
     int two_rounds;
@@ -701,6 +716,23 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
         r = S.chal;
     } else {
         r = fe_load<F>(a.ctx.proof, a.chal_base + a.per * a.round);
+    }
+    if (a.pending2) {                                        // fold by the first pending challenge; the second one is the `r` of what follows
+        const size_t ol = cl / 2;
+        char *d1 = (char *)a.buf[j & 1];
+        const Multiplier<F> mr(r);
+        for (size_t t = tid; t < (size_t)a.ntab * ol; t += kTailBlock) {
+            const size_t k = t / ol, idx = t - k * ol;
+            if (a.tabs.in[k] == nullptr) continue;
+            const Fe<F> x = fe_load<F>(a.tabs.in[k], idx), y = fe_load<F>(a.tabs.in[k], idx + ol);
+            fe_store<F>(d1 + k * ol * esz, idx, fe_add<F>(x, mr.times(fe_sub<F>(y, x))));
+        }
+        __syncthreads();
+        prev = d1;
+        cl = ol;
+        round++;
+        j++;
+        r = fe_load<F>(a.ctx.proof, a.chal_base + a.per * round);
     }
     // Two rounds per exchange.  A round on a short table is latency: ~3 us of arithmetic, then the workgroup's reduction (2 us) and the exchange with the
     // host (3.4 us) -- and the round AFTER it is a polynomial in this round's challenge whose coefficients are known before the challenge is.  With the

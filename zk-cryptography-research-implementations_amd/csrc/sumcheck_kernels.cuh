@@ -50,6 +50,7 @@ struct RoundFin {
     void *proof;
     size_t chal_slot;
     uint32_t *exp_out;       // non-null: the challenge also leaves as a uniform multiplier (ufield.cuh UniMul, L x L words) for the fused round that folds by it
+    size_t per2;             // non-zero: a TWO-round exchange (split2_round_kernel): the npts = 9 sums go out together, two challenges come back, to chal_slot and chal_slot + per2
 };
 // wave 0 of every workgroup calls this; lane t < npts holds the workgroup's sum of evaluation t in `tot` (stored form, fully reduced)
 template <class F> __device__ __forceinline__ void round_finish_in_producer(const RoundFin &f, const Fe<F> &tot);   // dev_transcript.cuh
@@ -481,6 +482,66 @@ __global__ void __launch_bounds__(512) fold_round_evals_split_kernel(SumPolyTabl
     if (fin.counter) {
         if (threadIdx.x < 64) round_finish_in_producer<F>(fin, tot);
     } else if (have) fe_store<F>(partials, (size_t)threadIdx.x * gridDim.x + blockIdx.x, tot);
+}
+
+// TWO rounds per launch and exchange on short tables of two products of two factors (the tail's scheme, dev_transcript.cuh sumcheck_tail_kernel, grid-wide):
+// the tables are folded by the ONE challenge (rp1 == null: 8 qq entries in) or the TWO challenges (16 qq entries in) that are pending, to T of 4 qq entries,
+// and the nine sums over the quads (T[i], T[i + qq] | T[i + 2 qq], T[i + 3 qq]) that carry the next two rounds leave in one exchange.
+// Workgroup = 1024 lanes = 64 quads: wave (k, e) folds entry e of table k's quad (three folds at most), the entries meet in LDS, then wave w takes the
+// (sum, product) pairs w and w + 16 of the 9 x 2.  Seven single split rounds and the tail's two longest rounds (131 us) become four of these.
+template <class F>
+__global__ void __launch_bounds__(1024) split2_round_kernel(SumPolyTables tabs, size_t qq, const void *__restrict__ rp0, const void *__restrict__ rp1, RoundFin fin) {
+    __shared__ Fe<F> exch[16 * 64];                            // [(k * 4 + e) * 64 + lane]
+    __shared__ Wide<F> part[18];
+    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63u, k = w >> 2, e = w & 3u;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;           // qq is a multiple of 64
+    const void *src = tabs.in[k];
+    Fe<F> v;
+    if (src == nullptr) {                                      // constant factor (wave-uniform)
+        v = const_factor<F>(tabs, (int)(k >> 1));
+    } else {
+        const Multiplier<F> m0(fe_load<F>(rp0, 0));
+        const size_t j = (size_t)e * qq + i;
+        if (rp1 == nullptr) {
+            const Fe<F> x = fe_load<F>(src, j), y = fe_load<F>(src, j + 4 * qq);
+            v = fe_add<F>(x, m0.times(fe_sub<F>(y, x)));
+        } else {
+            const Fe<F> x0 = fe_load<F>(src, j), y0 = fe_load<F>(src, j + 8 * qq), x1 = fe_load<F>(src, j + 4 * qq), y1 = fe_load<F>(src, j + 12 * qq);
+            const Fe<F> l0 = fe_add<F>(x0, m0.times(fe_sub<F>(y0, x0))), l1 = fe_add<F>(x1, m0.times(fe_sub<F>(y1, x1)));
+            const Multiplier<F> m1(fe_load<F>(rp1, 0));
+            v = fe_add<F>(l0, m1.times(fe_sub<F>(l1, l0)));
+        }
+        fe_store<F>(tabs.out[k], j, v);
+    }
+    exch[w * 64 + lane] = v;
+    __syncthreads();
+#pragma unroll 1
+    for (unsigned t = w; t < 18; t += 16) {                    // (sum, product) pair t: sum t % 9 of product t / 9
+        const unsigned kind = t % 9u, p = t / 9u;
+        Fe<F> o[2];
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            const Fe<F> *q4 = exch + (size_t)((p * 2 + f) * 4) * 64 + lane;           // a, b, c, d at q4[0], q4[64], q4[128], q4[192]
+            if (kind < 4) o[f] = q4[kind * 64];
+            else if (kind < 8) {
+                const unsigned hi = kind == 4 ? 2 : kind == 5 ? 3 : kind == 6 ? 1 : 3, lo = kind == 4 ? 0 : kind == 5 ? 1 : kind == 6 ? 0 : 2;
+                o[f] = fe_sub<F>(q4[hi * 64], q4[lo * 64]);
+            } else o[f] = fe_sub<F>(fe_sub<F>(q4[192], q4[128]), fe_sub<F>(q4[64], q4[0]));
+        }
+        Wide<F> acc[1] = {wide_zero<F>()};
+        wide_add_fe<F>(acc[0], fe_mul<F>(o[0], o[1]));
+        wave_reduce_wide<F, 1>(acc);
+        if (lane == 63) part[t] = acc[0];
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    Fe<F> tot = fe_zero<F>();
+    if (lane < 9) {
+        Wide<F> s2 = part[lane];
+        wide_add<F>(s2, part[9 + lane]);
+        tot = wide_reduce<F>(s2);
+    }
+    round_finish_in_producer<F>(fin, tot);
 }
 
 // element-wise reduce of a SumPolynomial to one table: out[i] = sum_p prod_f X[p][f][i]

@@ -482,6 +482,16 @@ template <class F> struct DeviceRounds {
                         chal_slot, expand ? uexp() : nullptr};
         return ZK_OK;
     }
+    // a TWO-round exchange in the last workgroup of split2_round_kernel: nine sums out, the challenges of rounds `first` and `first + 1` back
+    // (messages at msg_slot, msg_slot + per; challenges at chal_slot, chal_slot + per)
+    int round2_fin(int grid, size_t msg_slot, size_t chal_slot, size_t per, RoundFin *out) {
+        if (!host_mode) return ZK_E_ARG;
+        push_req(Req{kRound2, 1, 3, 0, 0, 0, 0, msg_slot, chal_slot, 0, {per, 0, 0, 0, 0, 0, 0}});
+        unsigned group = 32;
+        while ((unsigned)(grid + group - 1) / group > 200u) group *= 2;
+        *out = RoundFin{(unsigned *)syncw, (uint64_t *)((char *)syncw + kSyncCounterBytes), 9, 0, group, nullptr, mb_dev, (uint64_t)nreq(), proof(), chal_slot, nullptr, per};
+        return ZK_OK;
+    }
     // the same for a sharded table: the kernel's last workgroup leaves the npts sums as limb words for the all-reduce, nothing is posted
     RoundFin round_fin_limbs(int grid, int npts, int skip1, uint64_t *limbs_out) const {
         unsigned group = 32;
@@ -532,11 +542,12 @@ template <class F> struct DeviceRounds {
     // first_evals: the tail starts with round `round`'s own evaluations and exchange (no round_evals launch in front of it); with_claim /
     // claim_slot as for that round
     int launch_tail(const SumPolyTables &tabs, void *buf0, void *buf1, int nprod, int nfac, size_t len, int mode, size_t round,
-                    size_t msg_base, size_t chal_base, size_t per, size_t fin_slot, int first_evals = 0, int with_claim = 0, size_t claim_slot = 0) {
+                    size_t msg_base, size_t chal_base, size_t per, size_t fin_slot, int first_evals = 0, int with_claim = 0, size_t claim_slot = 0,
+                    int pending2 = 0) {
         TailArgs a{};
         a.tabs = tabs; a.buf[0] = buf0; a.buf[1] = buf1; a.nprod = nprod; a.ntab = nprod * nfac; a.len = len;
         a.ctx = ctx(nfac + 1, mode); a.round = round; a.msg_base = msg_base; a.chal_base = chal_base; a.per = per; a.fin_slot = fin_slot;
-        a.first_evals = first_evals; a.with_claim = with_claim; a.claim_slot = claim_slot;
+        a.first_evals = first_evals; a.with_claim = with_claim; a.claim_slot = claim_slot; a.pending2 = pending2;
         // ZK_TAIL_TWO_ROUNDS = the most (product, quad) pairs a two-round exchange takes (0: never; measurement / fallback switch)
         static const int two = [] { const char *e = getenv("ZK_TAIL_TWO_ROUNDS"); int v = e ? atoi(e) : 128; return v < 0 ? 0 : (v > 4096 ? 4096 : v); }();   // r4 sweep (0 / 64 / 128 / 256 / 512): 4 x 2^12 0.155 / 0.145 / 0.134 / 0.139 / 0.139 ms, depth-8 GKR 1.26 / 1.20 / 1.18 / 1.17 / 1.18
         a.two_rounds = (host_mode && nfac == 2 && mode == 1) ? two : 0;
@@ -552,7 +563,9 @@ template <class F> struct DeviceRounds {
             if (first_evals)                                 // round `round` itself: the request round_fin() would have registered for a launch of its own
                 push_req(Req{kRound, mode, nfac + 1, with_claim, 0, 0, claim_slot, msg_base + per * rd, chal_base + per * rd, 0, {0, 0, 0, 0, 0, 0, 0}});
             // the kernel's own schedule (dev_transcript.cuh): single rounds while the tables are long, two rounds per exchange once (product, quad) pairs fit a wave
-            for (size_t cl = len; cl >= 4;) {
+            size_t cl0 = len;
+            if (pending2) { cl0 = len / 2; rd++; }           // the kernel folds by the first pending challenge before its first exchange
+            for (size_t cl = cl0; cl >= 4;) {
                 if (a.two_rounds && cl >= 8 && (size_t)nprod * (cl / 8) <= (size_t)a.two_rounds) {
                     push_req(Req{kRound2, mode, nfac + 1, 0, 0, 0, 0, msg_base + per * (rd + 1), chal_base + per * (rd + 1), 0, {per, 0, 0, 0, 0, 0, 0}});
                     rd += 2;
@@ -985,8 +998,13 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
     // The fused round of the two-factor lazy kernel folds by the challenge as a UNIFORM multiplier (ufield.cuh UniMul); the exchange that receives
     // the challenge of a round whose fold is such a launch leaves it in that form (host-assisted step; otherwise the kernel's waves work it out).
     const size_t tail_from0 = (nfac == 2 && nprod >= 2) ? kTailLen / 2 : kTailLen;
+    // ZK_GRID_TWO_ROUNDS=0: the short grid-wide rounds stay one round per launch (measurement / fallback switch)
+    static const bool grid_two = [] { const char *e = getenv("ZK_GRID_TWO_ROUNDS"); return !(e && e[0] == '0'); }();
+    static const size_t grid_two_max_q = [] { const char *e = getenv("ZK_GRID_TWO_BITS"); int b = e ? atoi(e) : 17; return (size_t)1 << (b < 6 ? 6 : (b > 24 ? 24 : b)); }();   // r4 sweep, 4 x 2^22 (15 / 16 / 17 / 18 / 19): 0.710 / 0.724 / 0.692 / 0.731 / 0.741 ms
+    const bool two_regime_ok = grid_two && dr.host_mode && nfac == 2 && nprod == 2;
     auto takes_uniform = [&](size_t cl_folded) {                     // cl_folded: the length of the tables that challenge folds
-        return dr.host_mode && nfac == 2 && LazyProducts<F>::value && cl_folded > tail_from0 && !fold_round_takes_split((int)nprod, (int)nfac, cl_folded / 4, true);
+        return dr.host_mode && nfac == 2 && LazyProducts<F>::value && cl_folded > tail_from0 && !fold_round_takes_split((int)nprod, (int)nfac, cl_folded / 4, true) &&
+               !(two_regime_ok && cl_folded >= 512 && cl_folded / 4 <= grid_two_max_q && (ilog2(cl_folded) & 1u));
     };
     const bool tail_takes_all = len <= tail_from0;                   // every round, the first one's evaluations included, in the one-workgroup tail
     if (!tail_takes_all) {   // round 0 evaluations
@@ -1012,6 +1030,33 @@ template <class F> int gkr_rounds_enqueue(DeviceRounds<F> &dr, size_t s0, const 
     for (; cl > tail_from; round++) {                                  // :37
         const void *rp = dr.slot_ptr(s0 + per * round + npts);         // :55, on the device
         size_t ol = cl / 2, q = cl / 4;
+        // (entered at an ODD log2 of the table length: the launches then end on 2^10 entries, which is where the one-workgroup tail is cheapest to enter)
+        if (two_regime_ok && cl >= 512 && q <= grid_two_max_q && (ilog2(cl) & 1u)) {
+            // From here down to the tail: TWO rounds per launch and exchange (sumcheck_kernels.cuh split2_round_kernel).  The first launch folds by the one
+            // pending challenge; every later one by the two its predecessor's exchange brought; the tail starts by folding with the first of its two.
+            auto launch2 = [&](size_t in_len, size_t first_new_round, const void *rp0, const void *rp1) -> int {
+                const size_t out_len = rp1 ? in_len / 4 : in_len / 2, qq = out_len / 4;
+                for (size_t k = 0; k < ntab; k++) tabs.out[k] = tables[k] ? dst + k * out_len * esz : nullptr;
+                RoundFin fin;
+                ZK_TRY(dr.round2_fin((int)(qq / 64), s0 + per * first_new_round, s0 + per * first_new_round + npts, per, &fin));
+                split2_round_kernel<F><<<(unsigned)(qq / 64), 1024, 0, cur_stream()>>>(tabs, qq, rp0, rp1, fin);
+                ZK_HIP(hipGetLastError());
+                for (size_t k = 0; k < ntab; k++) tabs.in[k] = tabs.out[k];
+                char *nx = other;
+                other = dst;
+                dst = nx;
+                return ZK_OK;
+            };
+            ZK_TRY(launch2(cl, round + 1, rp, nullptr));               // challenges of rounds round + 1, round + 2 come back
+            cl = ol;
+            size_t R = round + 1;                                      // the first of the two pending challenges
+            while (cl > kTailLen) {                                    // 16 qq entries in, qq >= 128
+                ZK_TRY(launch2(cl, R + 2, dr.slot_ptr(s0 + per * R + npts), dr.slot_ptr(s0 + per * (R + 1) + npts)));
+                cl /= 4;
+                R += 2;
+            }
+            return dr.launch_tail(tabs, dst, other, (int)nprod, (int)nfac, cl, 1, R, s0, s0 + npts, per, fin_slot, 0, 0, 0, 1);
+        }
         for (size_t k = 0; k < ntab; k++) tabs.out[k] = tables[k] ? dst + k * ol * esz : nullptr;
         int grid = reduce_grid_for(q);                                 // :57 fused with next round's :41
         // large rounds skip the products of the point 1: e(1) = p_round(r_round) - e(0), derived in the finish step
