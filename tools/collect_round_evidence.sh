@@ -6,10 +6,10 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/p_fold -- python3 $R/
 python3 $R/tools/rocprof_summary.py /tmp/p_fold fold0_kernel > $R/gpurun_out/r4e/fold_2p24_kernel_summary.txt 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/p_gkr -- python3 $R/tools/profile_gkr_round.py 22 20 > $R/gpurun_out/r4e/gkr_run.log 2>&1
 python3 $R/tools/rocprof_summary.py /tmp/p_gkr fold_round_evals_kernel round_evals_kernel > $R/gpurun_out/r4e/gkr_sumcheck_2p22_kernel_summary.txt 2>&1
-python3 $R/tools/rocprof_timeline.py /tmp/p_gkr 15 "round_evals_kernel<zk::Fr381, 2, false>" > $R/gpurun_out/r4e/gkr_sumcheck_2p22_timeline.txt 2>&1
+python3 $R/tools/rocprof_timeline.py /tmp/p_gkr 11 "round_evals_kernel<zk::Fr381, 2, false>" > $R/gpurun_out/r4e/gkr_sumcheck_2p22_timeline.txt 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python3 $R/tools/bench_gkr_sparse.py 22 3 random > $R/gpurun_out/r4e/sparse_run.log 2>&1
 python3 $R/tools/rocprof_summary.py /tmp/p_sp fold_round_evals_kernel > $R/gpurun_out/r4e/gkr_sparse_config4_kernel_summary.txt 2>&1
-python3 $R/tools/rocprof_timeline.py /tmp/p_sp 33 "phase1_tables_kernel<zk::Fr381, true>" > $R/gpurun_out/r4e/gkr_sparse_config4_layer_timeline.txt 2>&1
+python3 $R/tools/rocprof_timeline.py /tmp/p_sp 24 "phase1_tables_kernel<zk::Fr381, true>" > $R/gpurun_out/r4e/gkr_sparse_config4_layer_timeline.txt 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/p_b24 -- python3 $R/tools/profile_config5_sumcheck.py 24 > $R/gpurun_out/r4e/basic_run.log 2>&1
 python3 $R/tools/rocprof_timeline.py /tmp/p_b24 4 "seg_sums_kernel" > $R/gpurun_out/r4e/basic_sumcheck_2p24_trace.txt 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/p_gd -- python3 $R/tools/profile_gkr_dense.py 8 5 > $R/gpurun_out/r4e/gkr_dense_run.log 2>&1
