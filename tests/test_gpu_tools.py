@@ -17,3 +17,17 @@ def test_quad_point_operations_and_weighted_sums_by_bits():
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
     assert "mismatch mask 0x0" in p.stdout and p.stdout.count(": ok") == 32 and "DIFFERS" not in p.stdout
+
+
+@pytest.mark.parametrize("args", [["16", "3", "256"], ["18", "3", "1536", "3"]])
+def test_round_kernels_alone_against_plain_kernels(args):
+    """tools/microbench_round.bin: the two GKR round kernels (csrc/sumcheck_kernels.cuh: uniform-multiplier fold, lazy sums, nodes 0 / 1 / infinity) launched on
+    their own, the folded tables byte for byte and the sums mod p against plain kernels written in the tool (general field product, one modular operation
+    after the other) -- on 4 tables and on 3 tables + a constant factor, with the multiplier read and worked out per wave"""
+    import json
+    exe = os.path.join(ROOT, "tools", "microbench_round.bin")
+    assert os.path.exists(exe), "tools/microbench_round.bin is built by __graft_entry__.build()"
+    p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
+    checked = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{") and "matches_reference" in ln]
+    assert len(checked) == 6 and all(c["matches_reference"] for c in checked), p.stdout[-3000:]
