@@ -447,7 +447,7 @@ def run_rank(env, args, zk):
         "collectives": env.collectives,
     }
     failed = []
-    for rnd in ("r3", "r2", "r1"):                           # PMC passes are separate rocprofv3 runs (committed summary)
+    for rnd in ("r4", "r3", "r2", "r1"):                     # PMC passes are separate rocprofv3 runs (committed summary)
         pmc = os.path.join(ROOT, "profiles", rnd, "fold_2p24_pmc.json")
         if n == 1 << 24 and os.path.exists(pmc):
             with open(pmc) as f:
