@@ -49,7 +49,8 @@ def main():
     comm.close()
     # GKR sumcheck (sumcheck_gkr_protocol.rs:24-67)
     MP = zk.MultilinearPolynomial
-    for field, (nprod, nfac, logn) in ((0, (2, 2, 5)), (0, (2, 2, 12)), (2, (3, 2, 13)), (0, (2, 3, 12)), (0, (2, 2, 16))):
+    # (2^11 .. 2^19 with two products of two factors: every way into and out of the two-rounds-per-launch regime, sumcheck_kernels.cuh split2_round_kernel)
+    for field, (nprod, nfac, logn) in ((0, (2, 2, 5)), (0, (2, 2, 11)), (0, (2, 2, 12)), (2, (3, 2, 13)), (0, (2, 3, 12)), (0, (2, 2, 16)), (2, (2, 2, 17)), (0, (2, 2, 19)), (0, (4, 2, 10))):
         n = 1 << logn
         tabs = np.stack([np.stack([rand_table(field, n, 60 * p + f + logn) for f in range(nfac)]) for p in range(nprod)])
         sp = zk.SumPolynomial([zk.ProductPolynomial([MP(field, t) for t in prod]) for prod in tabs])
@@ -107,6 +108,24 @@ def main():
         checked += 1
         if not zk.gkr.sparse_verify(fld, rows2, [lg2] * 2, proof3, x3):
             bad.append(["sparse_gkr_verify_field", fld])
+    # gkr_protocol::prove through the dense API (from the gate lists, or on the dense tables with ZK_GKR_DENSE_TABLES=1): the oracle's proof
+    import random
+    prng = random.Random(66)
+    layers = []
+    for i in range(6):
+        n_in = 1 << (i + 1)
+        layers.append([(prng.randrange(n_in), prng.randrange(n_in), o, prng.choice([0, 1])) for o in range(1 << i)])
+    xin = rand_table(0, 1 << 6, 4500)
+    circuit = zk.gkr.Circuit(0, [zk.gkr.Layer([zk.gkr.Gate(*g) for g in layer]) for layer in layers])
+    gp = zk.gkr.prove(circuit, xin)
+    want = O.gkr_prove(0, layers, xin)
+    claims, co, ch = gp._flat
+    checked += 1
+    if not (np.array_equal(claims, want["layer_claims"]) and np.array_equal(co, want["coeffs"]) and np.array_equal(ch, want["challenges"])
+            and np.array_equal(gp.wb_evaluations, want["wb_evals"]) and np.array_equal(gp.wc_evaluations, want["wc_evals"]) and zk.gkr.verify(circuit, gp, xin)):
+        bad.append(["gkr_dense_api"])
+    for arr in (claims, co, ch):
+        h.update(np.ascontiguousarray(arr).tobytes())
     print(json.dumps({"checked": checked, "mismatches": bad, "sparse_gkr_digest": h.hexdigest(), "env": {k: v for k, v in os.environ.items() if k.startswith("ZK_")}}), flush=True)
 
 

@@ -1,7 +1,8 @@
 """The environment switches that select another code path for the same result -- the transcript step on the device
 (ZK_HOST_TRANSCRIPT=0), the rounds-per-pass cap of the basic sumcheck (ZK_BASIC_ROUNDS_PER_PASS, csrc/basic_multi.cuh) and the sparse GKR
-prover's gate weights from a table instead of the eq half tables (ZK_GKR_WEIGHT_TABLE=1, csrc/zkmle_gkr_sparse.hip) -- are read
-once per process: each variant runs tests/_variant_worker.py in a child process and must reproduce the oracle's proofs."""
+prover's gate weights from a table instead of the eq half tables (ZK_GKR_WEIGHT_TABLE=1, csrc/zkmle_gkr_sparse.hip), one or two GKR rounds per
+launch / exchange (ZK_GRID_TWO_ROUNDS, ZK_GRID_TWO_BITS, ZK_TAIL_TWO_ROUNDS: r4), the dense API on its dense tables (ZK_GKR_DENSE_TABLES=1) -- are read
+once per process (the last one per call): each variant runs tests/_variant_worker.py in a child process and must reproduce the oracle's proofs."""
 import json
 import os
 import subprocess
@@ -18,8 +19,11 @@ DIGESTS = {}
 
 @pytest.mark.parametrize("env", [{}, {"ZK_HOST_TRANSCRIPT": "0"}, {"ZK_BASIC_ROUNDS_PER_PASS": "1"}, {"ZK_BASIC_ROUNDS_PER_PASS": "2"},
                                  {"ZK_BASIC_ROUNDS_PER_PASS": "3"}, {"ZK_BASIC_ROUNDS_PER_PASS": "4"}, {"ZK_BASIC_ROUNDS_PER_PASS": "6"},
-                                 {"ZK_BASIC_ROUNDS_PER_PASS": "8"}, {"ZK_GKR_WEIGHT_TABLE": "1"}],
-                         ids=["default", "device_step", "k1", "k2", "k3", "k4", "k6", "k8", "weight_table"])
+                                 {"ZK_BASIC_ROUNDS_PER_PASS": "8"}, {"ZK_GKR_WEIGHT_TABLE": "1"},
+                                 {"ZK_GRID_TWO_ROUNDS": "0"}, {"ZK_TAIL_TWO_ROUNDS": "0"}, {"ZK_GRID_TWO_ROUNDS": "0", "ZK_TAIL_TWO_ROUNDS": "0"},
+                                 {"ZK_GRID_TWO_BITS": "13"}, {"ZK_TAIL_TWO_ROUNDS": "16"}, {"ZK_GKR_DENSE_TABLES": "1"}],
+                         ids=["default", "device_step", "k1", "k2", "k3", "k4", "k6", "k8", "weight_table",
+                              "grid_single_rounds", "tail_single_rounds", "single_rounds", "grid_two_from_2p13", "tail_two_upto_16_pairs", "dense_tables"])
 def test_variant_reproduces_oracle_proofs(env):
     e = dict(os.environ)
     e.update(env)
