@@ -746,13 +746,15 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
     // (zkmle_sumcheck.hip serve_round2: the same messages, the same bytes absorbed) and answers with both challenges.  One WAVE per sum: lane m of
     // wave s takes (product, quad) m of sum s -- one product per lane, one DPP reduction per wave; wave 0 takes the ninth sum as well.
     // (A first form with one lane per (product, quad) doing all nine products lost to the single rounds: 256 VGPRs, spills, a nine-sum reduction.)
-    __shared__ Fe<F> ev9[9], ch2[2];                         // two rounds per exchange (below)
+    __shared__ Wide<F> w9[9];                                // two rounds per exchange (below)
+    __shared__ Fe<F> ch2[2];
     const unsigned wv = tid >> 6;
     for (;;) {
         if constexpr (NFAC == 2) {
             while (mb && a.two_rounds && cl >= 8 && (size_t)a.nprod * (cl / 8) <= (size_t)a.two_rounds) {
                 const size_t ol = cl / 2, qq = ol / 4, o2 = ol / 2;
                 char *d1 = (char *)a.buf[j & 1], *d2 = (char *)a.buf[(j + 1) & 1];
+                ZK_TAIL_STAMP(0);
                 {   // fold by r: one lane task per (table, output index)
                     const Multiplier<F> mr(r);
                     for (size_t t = tid; t < (size_t)a.ntab * ol; t += kTailBlock) {
@@ -764,6 +766,7 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                     }
                 }
                 __syncthreads();
+                ZK_TAIL_STAMP(1);
                 {
                     const size_t M = (size_t)a.nprod * qq;                 // (product, quad) pairs: <= kTwoRoundPairs
 #pragma unroll 1
@@ -796,18 +799,21 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                             wide_add_fe<F>(acc[0], fe_mul<F>(o[0], o[1]));
                         }
                         wave_reduce_wide<F, 1>(acc);
-                        if (lane == 63) ev9[kind] = wide_reduce<F>(acc[0]);
+                        if (lane == 63) w9[kind] = acc[0];                 // the nine lazy sums are reduced together by the posting lanes
                     }
                 }
                 __syncthreads();
+                ZK_TAIL_STAMP(2);
                 if (tid < 64) {
                     if (lane < 9) {
+                        const Fe<F> e9 = wide_reduce<F>(w9[lane]);
     #pragma unroll
-                        for (int w = 0; w < F::N; w++) mb->big[lane * 12 + w] = ev9[lane].l[w];
+                        for (int w = 0; w < F::N; w++) mb->big[lane * 12 + w] = e9.l[w];
                     }
                     __threadfence_system();
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 0) __atomic_store_n(&mb->gpu_seq, seq, __ATOMIC_RELEASE);
+                    ZK_TAIL_STAMP(3);
                     const Fe<F> rr = mailbox_wait_challenges<F>(mb, seq, lane, 2u);
                     if (lane < 2) {
                         ch2[lane] = rr;
@@ -816,6 +822,7 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                     seq++;
                 }
                 __syncthreads();
+                ZK_TAIL_STAMP(4);
                 {   // fold T' by the first of the two challenges; the second one folds the result in the next iteration
                     const Multiplier<F> mr(ch2[0]);
                     for (size_t t = tid; t < (size_t)a.ntab * o2; t += kTailBlock) {
@@ -827,6 +834,7 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                     }
                 }
                 __syncthreads();
+                ZK_TAIL_STAMP(5);
                 r = ch2[1];
                 prev = d2;
                 cl = o2;

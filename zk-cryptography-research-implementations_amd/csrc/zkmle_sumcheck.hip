@@ -288,42 +288,45 @@ template <class F> struct DeviceRounds {
         hs[q.chal_slot] = r;
     }
     // one transcript step of a two-factor GKR round from its evaluations at 0, 1, infinity (sumcheck_gkr_protocol.rs:46-55): absorbs the coefficients
-    // (canonical, little-endian), samples the challenge, keeps the proof's copy and the running claim
-    Fe<F> step_gkr3(const Fe<F> (&ev)[3], size_t msg_slot, size_t chal_slot) {
+    // (canonical, little-endian) and samples the challenge -- only what the challenge depends on; keep_gkr3 does the bookkeeping afterwards
+    Fe<F> step_gkr3(const Fe<F> (&ev)[3]) {
         const size_t n2 = 9;
         uint8_t bytes[3 * 4 * F::N];
-        Fe<F> c[3];
         for (int d = 0; d < 3; d++) {
             Fe<F> cc = fe_mul<F>(ev[0], hbasis[n2 + d]);
-            c[d] = fe_mul<F>(ev[0], hbasis[d]);
-            for (int i = 1; i < 3; i++) {
-                cc = fe_add<F>(cc, fe_mul<F>(ev[i], hbasis[n2 + (size_t)i * 3 + d]));
-                c[d] = fe_add<F>(c[d], fe_mul<F>(ev[i], hbasis[(size_t)i * 3 + d]));
-            }
+            for (int i = 1; i < 3; i++) cc = fe_add<F>(cc, fe_mul<F>(ev[i], hbasis[n2 + (size_t)i * 3 + d]));
             memcpy(bytes + (size_t)d * 4 * F::N, cc.l, 4 * F::N);
-            hs[msg_slot + d] = c[d];
         }
         htr->append(bytes, sizeof bytes);
-        const Fe<F> r = htr->template random_challenge_as_field_element<F>();
+        return htr->template random_challenge_as_field_element<F>();
+    }
+    // the proof's copy of that round (coefficients in the stored form, the challenge) and the running claim
+    void keep_gkr3(const Fe<F> (&ev)[3], const Fe<F> &r, size_t msg_slot, size_t chal_slot) {
+        Fe<F> c[3];
+        for (int d = 0; d < 3; d++) {
+            c[d] = fe_mul<F>(ev[0], hbasis[d]);
+            for (int i = 1; i < 3; i++) c[d] = fe_add<F>(c[d], fe_mul<F>(ev[i], hbasis[(size_t)i * 3 + d]));
+            hs[msg_slot + d] = c[d];
+        }
         hs[chal_slot] = r;
         running_claim = fe_add<F>(fe_mul<F>(fe_add<F>(fe_mul<F>(c[2], r), c[1]), r), c[0]);
-        return r;
     }
     // TWO rounds of a two-factor GKR sumcheck from the nine sums the tail posts (dev_transcript.cuh, sumcheck_tail_kernel): round A's evaluations are sums of
-    // them; round B's are polynomials in round A's challenge with those sums as coefficients.  q.s[0] = slots per round.
+    // them; round B's are polynomials in round A's challenge with those sums as coefficients.  q.s[0] = slots per round.  The kernel is spinning: both
+    // challenges go out before any bookkeeping.
     void serve_round2(const Req &q, uint64_t seq) {
         Fe<F> S[9];
         for (int t = 0; t < 9; t++) S[t] = mb_get(mb->big + 12 * t);
         const Fe<F> &P0 = S[0], &P1 = S[1], &Q0 = S[2], &Q1 = S[3], &D0 = S[4], &D1 = S[5], &EE = S[6], &FF = S[7], &GG = S[8];
         const size_t per = q.s[0];
         const Fe<F> evA[3] = {fe_add<F>(P0, P1), fe_add<F>(Q0, Q1), fe_add<F>(D0, D1)};
-        const Fe<F> rA = step_gkr3(evA, q.msg_slot, q.chal_slot);
+        const Fe<F> rA = step_gkr3(evA);
         auto quad = [&](const Fe<F> &k0, const Fe<F> &k1, const Fe<F> &k2) {          // k0 + rA (k1 - k0 - k2) + rA^2 k2
             const Fe<F> mid = fe_sub<F>(fe_sub<F>(k1, k0), k2);
             return fe_add<F>(fe_mul<F>(fe_add<F>(fe_mul<F>(k2, rA), mid), rA), k0);
         };
         const Fe<F> evB[3] = {quad(P0, Q0, D0), quad(P1, Q1, D1), quad(EE, FF, GG)};
-        const Fe<F> rB = step_gkr3(evB, q.msg_slot + per, q.chal_slot + per);
+        const Fe<F> rB = step_gkr3(evB);
         const Fe<F> both[2] = {rA, rB};
         for (int i = 0; i < 2; i++)
             for (int k = 0; k < F::N; k++) __atomic_store_n(&mb->ans8[i][1 + k], both[i].l[k], __ATOMIC_RELAXED);
@@ -331,6 +334,8 @@ template <class F> struct DeviceRounds {
             __atomic_store_n(&mb->ans8[i][0], (uint32_t)seq, __ATOMIC_RELEASE);
             __atomic_store_n(&mb->ans8[i][15], (uint32_t)seq, __ATOMIC_RELEASE);
         }
+        keep_gkr3(evA, rA, q.msg_slot, q.chal_slot);
+        keep_gkr3(evB, rB, q.msg_slot + per, q.chal_slot + per);
     }
     // basic sumcheck, q.npts rounds from the 2^npts segment sums of the current table (basic_multi.cuh): the basic sumcheck on the
     // table of the sums, S -- round i sends its two half sums and folds its top variable by the challenge
@@ -603,9 +608,10 @@ template <class F> struct DeviceRounds {
     void print_tail_trace(size_t len) {
         uint64_t st[6 * 16];
         if (zk::memcpy_on_stream(st, tail_trace.p, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return;
-        static const char *names[5] = {"fold+terms", "reduce", "post", "wait", "sync"};
+        static const char *names[5] = {"fold+terms", "reduce", "post", "wait", "sync"};      // (a two-round iteration: fold, nine sums, post, wait, second fold)
         size_t cl = len;
-        for (int j = 0; cl >= 4 && j < 16; j++, cl /= 2) {
+        for (int j = 0; j < 16; j++) {
+            if (st[6 * j] == 0 && st[6 * j + 5] == 0) continue;
             fprintf(stderr, "tail round %2d (len %4zu):", j, cl);
             for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.2f us", names[k], (double)(st[6 * j + k + 1] - st[6 * j + k]) * 0.01);
             fprintf(stderr, " | total %.2f us\n", (double)(st[6 * j + 5] - st[6 * j]) * 0.01);
