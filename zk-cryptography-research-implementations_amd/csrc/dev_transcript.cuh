@@ -769,37 +769,51 @@ __global__ void __launch_bounds__(kTailBlock) sumcheck_tail_kernel(TailArgs a) {
                 ZK_TAIL_STAMP(1);
                 {
                     const size_t M = (size_t)a.nprod * qq;                 // (product, quad) pairs: <= kTwoRoundPairs
-#pragma unroll 1
-                    for (unsigned pass = 0; pass < 2; pass++) {            // every wave its own sum; wave 0 the ninth one after that
-                        if (pass == 1 && wv != 0) break;
-                        const unsigned kind = pass == 0 ? wv : 8u;
-                        Wide<F> acc[1] = {wide_zero<F>()};
-#pragma unroll 1
-                        for (size_t m = lane; m < M; m += 64) {
-                            const size_t p = m / qq, i = m - p * qq;
-                            // the operand pair of sum `kind` at this lane's quad: x (first factor), y (second factor); at most two entries of T' each
-                            // kinds: 0 P0 = a a', 1 P1 = b b', 2 Q0 = c c', 3 Q1 = d d', 4 D0 = (c-a)(..), 5 D1 = (d-b)(..), 6 EE = (b-a)(..), 7 FF = (d-c)(..), 8 GG = ((d-c)-(b-a))(..)
-                            Fe<F> o[2];
+                    // the operand pair (first factor, second factor) of sum `kind` at (product, quad) m
+                    // kinds: 0 P0 = a a', 1 P1 = b b', 2 Q0 = c c', 3 Q1 = d d', 4 D0 = (c-a)(..), 5 D1 = (d-b)(..), 6 EE = (b-a)(..), 7 FF = (d-c)(..), 8 GG = ((d-c)-(b-a))(..)
+                    auto term = [&](unsigned kind, size_t m) -> Fe<F> {
+                        const size_t p = m / qq, i = m - p * qq;
+                        Fe<F> o[2];
 #pragma unroll
-                            for (int f = 0; f < 2; f++) {
-                                if (a.tabs.in[p * 2 + f] == nullptr) {                     // a constant factor: a = b = c = d
-                                    o[f] = kind < 4 ? const_factor<F>(a.tabs, (int)p) : fe_zero<F>();
-                                    continue;
-                                }
-                                const void *tb = d1 + (p * 2 + f) * ol * esz;
-                                if (kind < 4) {
-                                    o[f] = fe_load<F>(tb, i + kind * qq);
-                                } else if (kind < 8) {
-                                    const size_t hi = kind == 4 ? 2 : kind == 5 ? 3 : kind == 6 ? 1 : 3, lo = kind == 4 ? 0 : kind == 5 ? 1 : kind == 6 ? 0 : 2;
-                                    o[f] = fe_sub<F>(fe_load<F>(tb, i + hi * qq), fe_load<F>(tb, i + lo * qq));
-                                } else {
-                                    o[f] = fe_sub<F>(fe_sub<F>(fe_load<F>(tb, i + 3 * qq), fe_load<F>(tb, i + 2 * qq)), fe_sub<F>(fe_load<F>(tb, i + qq), fe_load<F>(tb, i)));
-                                }
+                        for (int f = 0; f < 2; f++) {
+                            if (a.tabs.in[p * 2 + f] == nullptr) {                         // a constant factor: a = b = c = d
+                                o[f] = kind < 4 ? const_factor<F>(a.tabs, (int)p) : fe_zero<F>();
+                                continue;
                             }
-                            wide_add_fe<F>(acc[0], fe_mul<F>(o[0], o[1]));
+                            const void *tb = d1 + (p * 2 + f) * ol * esz;
+                            if (kind < 4) {
+                                o[f] = fe_load<F>(tb, i + kind * qq);
+                            } else if (kind < 8) {
+                                const size_t hi = kind == 4 ? 2 : kind == 5 ? 3 : kind == 6 ? 1 : 3, lo = kind == 4 ? 0 : kind == 5 ? 1 : kind == 6 ? 0 : 2;
+                                o[f] = fe_sub<F>(fe_load<F>(tb, i + hi * qq), fe_load<F>(tb, i + lo * qq));
+                            } else {
+                                o[f] = fe_sub<F>(fe_sub<F>(fe_load<F>(tb, i + 3 * qq), fe_load<F>(tb, i + 2 * qq)), fe_sub<F>(fe_load<F>(tb, i + qq), fe_load<F>(tb, i)));
+                            }
                         }
-                        wave_reduce_wide<F, 1>(acc);
-                        if (lane == 63) w9[kind] = acc[0];                 // the nine lazy sums are reduced together by the posting lanes
+                        return fe_mul<F>(o[0], o[1]);
+                    };
+                    if (M <= 32) {
+                        // short tables: TWO sums per wave, one in each half (lanes 0..31 / 32..63), nine sums in five waves and ONE pass; the half-wave sums are
+                        // what the row reduction and the first cross-row step leave in lanes 31 and 63
+                        const unsigned kind = 2 * wv + (lane >> 5), m = lane & 31u;
+                        if (wv < 5) {
+                            Wide<F> acc = wide_zero<F>();
+                            if (kind < 9 && m < M) wide_add_fe<F>(acc, term(kind, m));
+                            row_reduce_wide<F>(acc);
+                            wide_dpp_step<F, 0x142, 0xa>(acc);
+                            if ((lane & 31u) == 31u && kind < 9) w9[kind] = acc;
+                        }
+                    } else {
+#pragma unroll 1
+                        for (unsigned pass = 0; pass < 2; pass++) {        // every wave its own sum; wave 0 the ninth one after that
+                            if (pass == 1 && wv != 0) break;
+                            const unsigned kind = pass == 0 ? wv : 8u;
+                            Wide<F> acc[1] = {wide_zero<F>()};
+#pragma unroll 1
+                            for (size_t m = lane; m < M; m += 64) wide_add_fe<F>(acc[0], term(kind, m));
+                            wave_reduce_wide<F, 1>(acc);
+                            if (lane == 63) w9[kind] = acc[0];             // the nine lazy sums are reduced together by the posting lanes
+                        }
                     }
                 }
                 __syncthreads();
